@@ -1,0 +1,141 @@
+/*
+ * pbhip.h -- C ABI of libpbhip.so: the MI355X (gfx950) coherent-dedispersion hot path.
+ *
+ * The reference (theXYZT/pulsarbat) is pure Python and has no FFI/plugin registry; the
+ * drop-in boundary is its Python call surface.  Each entry point below replaces one
+ * numpy/scipy expression of the reference (cited file:line, relative to the reference
+ * root) and is what a binding for that expression would call.  INTEGRATION.md shows the
+ * ctypes stub a pulsarbat maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no C++/torch types.
+ *  - every function returns PBH_OK (0) or a negative pbh_status; it never throws and never
+ *    aborts.  pbh_last_error() returns a thread-local message for the last failure.
+ *  - arrays are C-contiguous, time (sample) axis first: (nsample, nchan, npol) complex64
+ *    exactly as BasebandSignal.data (pulsarbat/core.py:704-764).
+ *  - a pointer's residency is given by a pbh_loc argument.  Host buffers are borrowed for
+ *    the duration of the call.  Device buffers must live on the plan's device.
+ *  - a plan is not re-entrant (one in-flight call per plan); distinct plans may be used from
+ *    distinct threads.  All work of a plan is enqueued on its stream (default: the null
+ *    stream; pbh_plan_set_stream installs a caller stream, e.g. torch's current stream).
+ *    Calls with host buffers synchronise before returning; calls with device-only buffers
+ *    are asynchronous with respect to the host.
+ */
+#ifndef PBHIP_H
+#define PBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pbh_plan pbh_plan;
+
+typedef enum {
+    PBH_OK = 0,
+    PBH_ERR_INVALID = -1,     /* bad argument (NULL, non-positive size, bad enum)            */
+    PBH_ERR_UNSUPPORTED = -2, /* valid request this build cannot serve (e.g. nsample not 2^k) */
+    PBH_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString)    */
+    PBH_ERR_NOMEM = -4,       /* device or host allocation failed                             */
+    PBH_ERR_STATE = -5        /* call sequence error (e.g. dedisperse before a chirp is set)  */
+} pbh_status;
+
+typedef enum { PBH_HOST = 0, PBH_DEVICE = 1 } pbh_loc;
+
+typedef enum { PBH_C64 = 0 } pbh_dtype; /* complex64 only (float32 arithmetic, as scipy.fft on c64) */
+
+/* Detection modes (pulsarbat/core.py:766-774, 930-966). Output float32. */
+typedef enum {
+    PBH_DETECT_INTENSITY = 0,       /* re^2+im^2 per element: (n, nchan, npol)   core.py:773      */
+    PBH_DETECT_STOKES_I = 1,        /* |A|^2+|B|^2:           (n, nchan)         core.py:948/960  */
+    PBH_DETECT_STOKES_LINEAR = 2,   /* I,Q,U,V linear basis:  (n, nchan, 4)      core.py:941-951  */
+    PBH_DETECT_STOKES_CIRCULAR = 3  /* I,Q,U,V circular:      (n, nchan, 4)      core.py:953-963  */
+} pbh_detect_mode;
+
+/* Pass-structure choices (pbh_plan_set_variant).  See DESIGN.md "Kernels". */
+typedef enum {
+    PBH_VARIANT_AUTO = 0,
+    PBH_VARIANT_PLANAR5 = 1, /* de-interleave, column FFT, fused row pass, column IFFT, re-interleave+crop */
+    PBH_VARIANT_DIRECT3 = 2  /* column FFT straight from the interleaved block, fused row pass,
+                                column IFFT straight into the cropped interleaved output */
+} pbh_variant;
+
+typedef struct {
+    int64_t nsample, crop_start, crop_stop;
+    int32_t nchan, npol, device;
+    int32_t n1, n2;             /* nsample = n1 * n2 (n1 = 1: single-pass plan)              */
+    int32_t variant;            /* resolved pbh_variant                                       */
+    int32_t nkernel;            /* kernels per pbh_dedisperse call                            */
+    int64_t workspace_bytes;    /* device memory owned by the plan (workspace+chirp+tables)   */
+    double  alg_bytes_per_sample; /* SURVEY.md 8(d) accounting figure for this plan           */
+} pbh_plan_info_t;
+
+#define PBH_MAX_KERNELS 8
+
+/* ---- library ---------------------------------------------------------------------------- */
+int pbh_device_count(void);
+const char* pbh_last_error(void);
+const char* pbh_version(void);
+
+/* ---- plan ------------------------------------------------------------------------------- */
+/* One plan = one (nsample, nchan, npol) block geometry on one device + its chirp.  crop_start /
+ * crop_stop are the reference's start/stop (pulsarbat/transforms/dedispersion.py:130-131); the
+ * crop is fused into the last kernel, so only stop-start rows are written.                      */
+int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol,
+                    int dtype, int64_t crop_start, int64_t crop_stop);
+int pbh_plan_destroy(pbh_plan* plan);
+int pbh_plan_set_stream(pbh_plan* plan, void* hip_stream);
+int pbh_plan_set_variant(pbh_plan* plan, int variant);
+int pbh_plan_info(const pbh_plan* plan, pbh_plan_info_t* info);
+
+/* ---- chirp (transfer function) ------------------------------------------------------------- */
+/* Replaces _transfer_function for every channel of a signal, i.e. DispersionMeasure.
+ * chirp_from_signal (dedispersion.py:19-23, 59-75): float64 phase
+ *   f = chan_freq + fftfreq(nsample, dt);  phi = coeff * f * (1/ref - 1/f)^2  [cycles]
+ *   chirp = complex64(exp(-2 pi i phi))
+ * with coeff_hz = dispersion_constant * DM in s*Hz^2 (= DM / 2.41e-4 * 1e12).  The result stays
+ * device-resident inside the plan (in the plan's internal order).                                 */
+int pbh_chirp_generate(pbh_plan* plan, double coeff_hz, double dt_s,
+                       const double* chan_freq_hz /* [nchan] */, double ref_freq_hz);
+/* User-supplied chirp= of coherent_dedispersion (dedispersion.py:121-124): (nsample, nchan) c64. */
+int pbh_chirp_upload(pbh_plan* plan, const void* chirp_c64, int loc);
+/* The plan's chirp in natural order, (nsample, nchan) c64: what chirp_from_signal returns.       */
+int pbh_chirp_download(pbh_plan* plan, void* chirp_c64, int loc);
+/* Stand-alone DispersionMeasure.chirp_function (dedispersion.py:44-57): one channel, (nsample,). */
+int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t nsample, double dt_s,
+                       double center_freq_hz, double ref_freq_hz, void* chirp_c64, int loc);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* Replaces  x = ifft(fft(z.data, axis=0) * chirp, axis=0)[start:stop]  (dedispersion.py:125-133).
+ * in : (nsample, nchan, npol) c64;  out: (crop_stop-crop_start, nchan, npol) c64.                   */
+int pbh_dedisperse(pbh_plan* plan, const void* in_c64, void* out_c64, int in_loc, int out_loc);
+
+/* Same, followed by detection (core.py:766-774 / 930-966) and an nscrunch-fold sum over time of the
+ * cropped samples (tail dropped): out is float32 (nout, nchan[, npol|4]), nout = (stop-start)/nscrunch. */
+int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int nscrunch, int mode,
+                          int in_loc, int out_loc);
+
+/* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
+int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, int64_t nsample,
+               int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);
+
+/* Backs pb.fft.fft / pb.fft.ifft for device arrays (pulsarbat/fft.py:30-48 -> scipy.fft.fft/ifft,
+ * norm=None): c2c along axis 0 of a C-contiguous (n, batch) c64 array.                              */
+int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64, int64_t n,
+                int64_t batch, int inverse, int in_loc, int out_loc);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* Runs the plan's kernel sequence `iters` times on device-resident in/out with hipEvents between the
+ * kernels (on the plan's stream) and returns the mean milliseconds of each kernel.                    */
+int pbh_plan_profile(pbh_plan* plan, const void* in_dev, void* out_dev, int iters,
+                     float* ms_per_kernel /* [PBH_MAX_KERNELS] */, int* nkernel,
+                     const char** names /* [PBH_MAX_KERNELS], static strings */);
+
+/* Device-to-device streaming copy of `bytes` (float4 per lane): the achievable-HBM reference number. */
+int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBHIP_H */

@@ -1,0 +1,198 @@
+"""CPU ORACLE for the coherent-dedispersion hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy/scipy.fft restatement of the reference algorithm
+(theXYZT/pulsarbat @ v0.0.10-dev1).  It exists to CHECK the HIP path; it is
+never the thing measured or shipped.  Only ``tests/``, ``__graft_entry__.smoke``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product package
+(``pulsarbat_amd``) must not import anything under ``oracle/``.
+
+Why a restatement and not the reference itself
+----------------------------------------------
+The reference is pure Python whose arithmetic lives in third-party wheels:
+``scipy.fft`` (pocketfft), ``numpy`` ufuncs and ``astropy.units`` for unit
+scaling (reference ``setup.py:8-12`` pins numpy>=1.26, scipy>=1.13,
+astropy>=6.1, dask>=2024.5).  numpy 2.2.6 and scipy 1.15.3 are present here and
+satisfy the pins, so this oracle calls *the same* FFT and ufunc routines the
+reference calls.  astropy/dask are absent (ordinary ModuleNotFoundError, not a
+permission denial), so ``import pulsarbat`` fails and astropy's unit algebra
+is replaced below by explicit SI constants.
+
+Pinning
+-------
+The reference ships no stored golden vectors for this path (all of its tests
+are known-answer scalars or properties).  The oracle is pinned against every
+known-answer / property test the reference holds for the path, in
+``tests/test_oracle.py``:
+  * tests/test_dedispersion.py:13-32   DM=2.41e-4 delay table (known answers)
+  * tests/test_dedispersion.py:73-98   reversibility, seeds {4,8,15,16,23,42}, atol 3e-8
+  * tests/test_dedispersion.py:100-139 Gabor-wavelet re-alignment (physics known answer)
+  * tests/test_dedispersion.py:141-164 precomputed chirp (2-D and 3-D) equivalence
+  * tests/test_dedispersion.py:36-71   crop length / start offset inequalities
+  * tests/test_polarization.py:38-48   hand-computed Stokes vectors
+  * tests/test_radio_signal.py:142-172 to_intensity dtype c64->f32, c128->f64
+
+Every function cites the reference file:line it follows (paths relative to
+the reference root).
+"""
+
+import math
+
+import numpy as np
+import scipy.fft
+
+# pulsarbat/transforms/dedispersion.py:30
+#   dispersion_constant = u.s * u.MHz**2 * u.cm**3 / u.pc / 2.41e-4
+DISPERSION_CONSTANT = 1.0 / 2.41e-4  # s MHz^2 cm^3 / pc
+
+
+def time_delay(dm, f_hz, ref_hz):
+    """pulsarbat/transforms/dedispersion.py:32-36 (DispersionMeasure.time_delay).
+
+    delay = D * DM * (1/f^2 - 1/ref^2), returned in seconds.  ``f_hz`` / ``ref_hz``
+    may be numpy.inf (tests/test_dedispersion.py:17-21) or arrays.
+    """
+    f_mhz = np.asarray(f_hz, dtype=np.float64) / 1e6
+    r_mhz = np.asarray(ref_hz, dtype=np.float64) / 1e6
+    with np.errstate(divide="ignore"):
+        return DISPERSION_CONSTANT * dm * (1.0 / f_mhz ** 2 - 1.0 / r_mhz ** 2)
+
+
+def sample_delay(dm, f_hz, ref_hz, sample_rate_hz):
+    """pulsarbat/transforms/dedispersion.py:38-42 (DispersionMeasure.sample_delay)."""
+    return time_delay(dm, f_hz, ref_hz) * sample_rate_hz
+
+
+def channel_freqs(center_freq_hz, chan_bw_hz, nchan, freq_align="center"):
+    """pulsarbat/core.py:569-574 (RadioSignal.channel_freqs), with the odd-nchan
+    rule of pulsarbat/core.py:561-567 (freq_align forced to 'center')."""
+    if freq_align not in {"bottom", "center", "top"}:
+        raise ValueError("Invalid freq_align.")
+    if nchan % 2:
+        freq_align = "center"
+    _align = {"bottom": 0, "center": 0.5, "top": 1}[freq_align]
+    chan_ids = np.arange(nchan) + _align - nchan / 2
+    return center_freq_hz + chan_bw_hz * chan_ids
+
+
+def band_edges(center_freq_hz, chan_bw_hz, nchan):
+    """pulsarbat/core.py:546-554 (max_freq / min_freq): returns (min, max)."""
+    bw = chan_bw_hz * nchan
+    return center_freq_hz - bw / 2, center_freq_hz + bw / 2
+
+
+def transfer_function(dm, N, dt_s, center_freq_hz, ref_freq_hz):
+    """pulsarbat/transforms/dedispersion.py:19-23 (_transfer_function).
+
+    f     = center_freq + fftfreq(N, dt)                      [Hz]   (:20)
+    phase = coeff * f * cycle * (1/ref_freq - 1/f)**2         [cycle] (:21)
+    tf    = exp(-1j * phase[rad]).astype(complex64)                    (:22-23)
+    with coeff = dispersion_constant * DM (:46) = D*DM s MHz^2 = D*DM*1e12 s Hz^2.
+    All float64 until the final cast, as in the reference.
+    """
+    coeff = DISPERSION_CONSTANT * dm * 1e12  # s Hz^2
+    f = center_freq_hz + np.fft.fftfreq(N, dt_s)
+    phase = coeff * f * (1.0 / ref_freq_hz - 1.0 / f) ** 2  # cycles
+    tf = np.exp(-1j * (2.0 * np.pi * phase))
+    return tf.astype(np.complex64)
+
+
+def phase_cycles(dm, N, dt_s, center_freq_hz, ref_freq_hz, bins):
+    """f64 phase (cycles) of transfer_function at selected FFT bins (for spot checks)."""
+    coeff = DISPERSION_CONSTANT * dm * 1e12
+    f = center_freq_hz + np.fft.fftfreq(N, dt_s)[np.asarray(bins)]
+    return coeff * f * (1.0 / ref_freq_hz - 1.0 / f) ** 2
+
+
+def chirp_from_signal(dm, shape, sample_rate_hz, center_freq_hz, freq_align="center",
+                      ref_freq_hz=None):
+    """pulsarbat/transforms/dedispersion.py:59-75 (chirp_from_signal).
+
+    One transfer function per channel frequency (:70-73), stacked on axis 1 and
+    given a length-1 axis for every signal axis >= 2 (:64, :75).
+    """
+    N, nchan = shape[0], shape[1]
+    ndim = len(shape)
+    if ref_freq_hz is None:
+        ref_freq_hz = center_freq_hz  # :67-68
+    dt = 1.0 / sample_rate_hz
+    ix = tuple(slice(None) if i < 2 else None for i in range(ndim))  # :64
+    freqs = channel_freqs(center_freq_hz, sample_rate_hz, nchan, freq_align)
+    chirps = [transfer_function(dm, N, dt, f, ref_freq_hz) for f in freqs]
+    return np.stack(chirps, axis=1)[ix]
+
+
+def crop_bounds(dm, N, nchan, sample_rate_hz, center_freq_hz, ref_freq_hz):
+    """pulsarbat/transforms/dedispersion.py:127-131: (start, stop)."""
+    fmin, fmax = band_edges(center_freq_hz, sample_rate_hz, nchan)
+    delay_top = float(sample_delay(dm, fmax, ref_freq_hz, sample_rate_hz))
+    delay_bot = float(sample_delay(dm, fmin, ref_freq_hz, sample_rate_hz))
+    start = math.ceil(-min(0, delay_top, delay_bot))
+    stop = N - math.ceil(+max(0, delay_top, delay_bot))
+    return start, stop
+
+
+def coherent_dedispersion(x, dm, sample_rate_hz, center_freq_hz, freq_align="center",
+                          ref_freq_hz=None, chirp=None, workers=None):
+    """pulsarbat/transforms/dedispersion.py:81-133 (coherent_dedispersion).
+
+    ``x`` is the BasebandSignal data, shape (nsample, nchan, ...), complex64 or
+    complex128 (pulsarbat/core.py:742).  Returns (y, start, stop) where ``y`` is
+    the cropped result ``x_full[start:stop]`` (:133) and the signal's start_time
+    advances by start/sample_rate (pulsarbat/core.py:155-164).
+
+    ``workers=None`` is what the reference executes (pulsarbat/fft.py:36-38 passes
+    nothing, so pocketfft runs single-threaded).
+    """
+    x = np.asarray(x)
+    if x.dtype not in (np.complex64, np.complex128):
+        raise TypeError("BasebandSignal data must be complex64/complex128 (core.py:742)")
+    if ref_freq_hz is None:
+        ref_freq_hz = center_freq_hz  # :118-119
+    if chirp is None:
+        chirp = chirp_from_signal(dm, x.shape, sample_rate_hz, center_freq_hz,
+                                  freq_align, ref_freq_hz)  # :121-122
+    chirp = chirp[(slice(None),) * chirp.ndim + (None,) * (x.ndim - chirp.ndim)]  # :124
+    y = scipy.fft.ifft(scipy.fft.fft(x, axis=0, workers=workers) * chirp, axis=0,
+                       workers=workers)  # :125
+    start, stop = crop_bounds(dm, x.shape[0], x.shape[1], sample_rate_hz,
+                              center_freq_hz, ref_freq_hz)  # :127-131
+    return y[start:stop], start, stop  # :133
+
+
+def to_intensity(z):
+    """pulsarbat/core.py:766-774 (BasebandSignal.to_intensity)."""
+    return z.real ** 2 + z.imag ** 2
+
+
+def to_stokes(z, pol_type):
+    """pulsarbat/core.py:930-966 (DualPolarizationSignal.to_stokes); pol axis = 2."""
+    A = np.take(z, 0, axis=2)
+    B = np.take(z, 1, axis=2)
+    AA = A.real ** 2 + A.imag ** 2
+    BB = B.real ** 2 + B.imag ** 2
+    AB = A.conj() * B
+    if pol_type == "linear":  # :941-951
+        i, Q, U, V = AA + BB, AA - BB, 2 * AB.real, 2 * AB.imag
+    elif pol_type == "circular":  # :953-963
+        i, Q, U, V = AA + BB, 2 * AB.real, 2 * AB.imag, AA - BB
+    else:
+        raise ValueError("pol_type must be in {'linear', 'circular'}")
+    return np.stack([i, Q, U, V], axis=2)
+
+
+def scrunch(a, nscrunch):
+    """Time-scrunch: sum of ``nscrunch`` consecutive time samples, tail dropped.
+
+    The reference has NO such function; the build defines it
+    as ``a[:n*k].reshape(n, k, ...).sum(1)`` in the array's own dtype.
+    """
+    n = a.shape[0] // nscrunch
+    return a[: n * nscrunch].reshape((n, nscrunch) + a.shape[1:]).sum(axis=1)
+
+
+def synthetic_block(shape, seed):
+    """SURVEY.md 8(d) synthetic input: complex standard normal / sqrt(2), complex64."""
+    rng = np.random.default_rng(seed)
+    re = rng.standard_normal(shape, dtype=np.float32)
+    im = rng.standard_normal(shape, dtype=np.float32)
+    return ((re + 1j * im) * np.float32(2 ** -0.5)).astype(np.complex64)

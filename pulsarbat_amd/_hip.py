@@ -1,0 +1,326 @@
+"""ctypes binding of libpbhip.so (the C ABI declared in include/pbhip.h).
+
+This is the only module that talks to the native library.  There is no CPU
+fallback anywhere behind it: if the library cannot be loaded, or no HIP device
+is present, every hot-path call raises :class:`HipUnavailableError`.
+"""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "fft_c2c",
+           "chirp_function", "copy_bench"]
+
+HOST, DEVICE = 0, 1
+DETECT_MODES = {"intensity": 0, "I": 1, "stokes_i": 1, "linear": 2, "circular": 3}
+VARIANTS = {"auto": 0, "planar5": 1, "direct3": 2}
+MAX_KERNELS = 8
+
+
+class HipError(RuntimeError):
+    """A libpbhip call failed (message from pbh_last_error)."""
+
+
+class HipUnavailableError(HipError):
+    """The HIP library or a HIP device is missing; the hot path cannot run."""
+
+
+class _PlanInfo(C.Structure):
+    _fields_ = [("nsample", C.c_int64), ("crop_start", C.c_int64), ("crop_stop", C.c_int64),
+                ("nchan", C.c_int32), ("npol", C.c_int32), ("device", C.c_int32),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("variant", C.c_int32),
+                ("nkernel", C.c_int32), ("workspace_bytes", C.c_int64),
+                ("alg_bytes_per_sample", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/pbhip.h declares
+SIGNATURES = {
+    "pbh_device_count": (C.c_int, []),
+    "pbh_last_error": (C.c_char_p, []),
+    "pbh_version": (C.c_char_p, []),
+    "pbh_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                  C.c_int64, C.c_int64]),
+    "pbh_plan_destroy": (C.c_int, [C.c_void_p]),
+    "pbh_plan_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pbh_plan_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "pbh_plan_info": (C.c_int, [C.c_void_p, C.POINTER(_PlanInfo)]),
+    "pbh_chirp_generate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double]),
+    "pbh_chirp_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pbh_chirp_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
+                                     C.c_double, C.c_void_p, C.c_int]),
+    "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pbh_detect": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_int]),
+    "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                              C.c_int, C.c_int]),
+    "pbh_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "pbh_copy_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded library (ctypes.CDLL releases the GIL during calls)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                path = os.environ.get("PBHIP_LIBRARY", _build.LIB)
+                if not os.path.exists(path):
+                    raise HipUnavailableError(
+                        f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(needs hipcc); pulsarbat_amd has no CPU fallback for the hot path")
+                # torch bundles its own libamdhip64.so.7; it must be loaded first so that
+                # libpbhip.so binds to that same runtime by SONAME (two HIP runtimes in one
+                # process leave the second without devices).
+                import torch  # noqa: F401
+                try:
+                    handle = C.CDLL(path)
+                except OSError as exc:
+                    raise HipUnavailableError(f"cannot load {path}: {exc}") from exc
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def available():
+    """True when the library loads and sees at least one HIP device."""
+    try:
+        return lib().pbh_device_count() > 0
+    except HipUnavailableError:
+        return False
+
+
+def _require_device():
+    n = lib().pbh_device_count()
+    if n <= 0:
+        raise HipUnavailableError("no HIP device visible; the hot path needs an MI355X (no CPU fallback)")
+    return n
+
+
+_ERRORS = {-1: ValueError, -2: NotImplementedError, -3: HipError, -4: MemoryError, -5: HipError}
+
+
+def _check(code):
+    if code != 0:
+        msg = lib().pbh_last_error().decode(errors="replace")
+        raise _ERRORS.get(code, HipError)(f"libpbhip: {msg} (status {code})")
+
+
+def _ptr_loc(a):
+    """(pointer, loc, keepalive) for a numpy array or a DeviceArray."""
+    from .device import DeviceArray
+    if isinstance(a, DeviceArray):
+        return C.c_void_p(a.data_ptr()), DEVICE
+    if isinstance(a, np.ndarray):
+        if not a.flags.c_contiguous:
+            raise ValueError("host arrays must be C-contiguous")
+        return C.c_void_p(a.ctypes.data), HOST
+    raise TypeError(f"unsupported array type {type(a)!r}")
+
+
+def _stream_ptr(device):
+    """torch's current stream on ``device`` so plan work is ordered with torch ops."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Plan:
+    """One (nsample, nchan, npol) block geometry + chirp on one device (pbh_plan)."""
+
+    def __init__(self, nsample, nchan, npol, crop_start, crop_stop, device=0, variant="auto",
+                 use_torch_stream=True):
+        _require_device()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        _check(lib().pbh_plan_create(C.byref(self._h), self.device, int(nsample), int(nchan), int(npol), 0,
+                                     int(crop_start), int(crop_stop)))
+        self.nsample, self.nchan, self.npol = int(nsample), int(nchan), int(npol)
+        self.crop_start, self.crop_stop = int(crop_start), max(int(crop_stop), int(crop_start))
+        self._use_torch_stream = use_torch_stream
+        if variant != "auto":
+            _check(lib().pbh_plan_set_variant(self._h, VARIANTS[variant]))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().pbh_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _sync_stream(self):
+        if self._use_torch_stream:
+            _check(lib().pbh_plan_set_stream(self._h, _stream_ptr(self.device)))
+
+    @property
+    def info(self):
+        inf = _PlanInfo()
+        _check(lib().pbh_plan_info(self._h, C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in _PlanInfo._fields_}
+
+    @property
+    def nout(self):
+        return self.crop_stop - self.crop_start
+
+    def chirp_generate(self, coeff_hz, dt_s, chan_freq_hz, ref_freq_hz):
+        self._sync_stream()
+        freqs = np.ascontiguousarray(chan_freq_hz, dtype=np.float64)
+        if freqs.shape != (self.nchan,):
+            raise ValueError("chan_freq_hz must have shape (nchan,)")
+        _check(lib().pbh_chirp_generate(self._h, float(coeff_hz), float(dt_s),
+                                        freqs.ctypes.data_as(C.POINTER(C.c_double)), float(ref_freq_hz)))
+
+    def chirp_upload(self, chirp):
+        self._sync_stream()
+        if tuple(chirp.shape) != (self.nsample, self.nchan) or chirp.dtype != np.complex64:
+            raise ValueError(f"chirp must be complex64 with shape {(self.nsample, self.nchan)}")
+        ptr, loc = _ptr_loc(chirp)
+        _check(lib().pbh_chirp_upload(self._h, ptr, loc))
+
+    def chirp_download(self, out=None):
+        self._sync_stream()
+        if out is None:
+            out = np.empty((self.nsample, self.nchan), dtype=np.complex64)
+        ptr, loc = _ptr_loc(out)
+        _check(lib().pbh_chirp_download(self._h, ptr, loc))
+        return out
+
+    def _check_in(self, x):
+        if tuple(x.shape[:1]) != (self.nsample,) or int(np.prod(x.shape[1:])) != self.nchan * self.npol:
+            raise ValueError(f"input shape {tuple(x.shape)} does not match plan "
+                             f"({self.nsample}, {self.nchan}, {self.npol})")
+        if x.dtype != np.complex64:
+            raise TypeError("input must be complex64")
+
+    def dedisperse(self, x, out=None):
+        """x: (nsample, nchan, npol) c64 numpy or DeviceArray -> (stop-start, ...) same container."""
+        from .device import DeviceArray
+        self._check_in(x)
+        self._sync_stream()
+        oshape = (self.nout,) + tuple(x.shape[1:])
+        if out is None:
+            if isinstance(x, DeviceArray):
+                out = DeviceArray.empty(oshape, np.complex64, device=self.device)
+            else:
+                out = np.empty(oshape, dtype=np.complex64)
+        pin, lin = _ptr_loc(x)
+        pout, lout = _ptr_loc(out)
+        _check(lib().pbh_dedisperse(self._h, pin, pout, lin, lout))
+        return out
+
+    def dedisperse_detect(self, x, nscrunch=1, mode="I", out=None):
+        from .device import DeviceArray
+        self._check_in(x)
+        self._sync_stream()
+        m = DETECT_MODES[mode]
+        tail = {0: (self.nchan, self.npol), 1: (self.nchan,), 2: (self.nchan, 4), 3: (self.nchan, 4)}[m]
+        oshape = (self.nout // int(nscrunch),) + tail
+        if out is None:
+            if isinstance(x, DeviceArray):
+                out = DeviceArray.empty(oshape, np.float32, device=self.device)
+            else:
+                out = np.empty(oshape, dtype=np.float32)
+        pin, lin = _ptr_loc(x)
+        pout, lout = _ptr_loc(out)
+        _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))
+        return out
+
+    def profile(self, x_dev, out_dev, iters=10):
+        """Mean per-kernel milliseconds (hipEvents on the plan's stream): list of (name, ms)."""
+        self._sync_stream()
+        ms = (C.c_float * MAX_KERNELS)()
+        names = (C.c_char_p * MAX_KERNELS)()
+        nk = C.c_int()
+        _check(lib().pbh_plan_profile(self._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(out_dev.data_ptr()),
+                                      int(iters), ms, C.byref(nk), names))
+        return [(names[i].decode(), float(ms[i])) for i in range(nk.value)]
+
+
+def detect(x, mode="intensity", nscrunch=1):
+    """to_intensity / to_stokes (+ optional time scrunch) of (n, nchan, npol) c64 data."""
+    from .device import DeviceArray
+    _require_device()
+    m = DETECT_MODES[mode]
+    n, nchan = x.shape[0], x.shape[1]
+    npol = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    if x.dtype != np.complex64:
+        raise TypeError("detect needs complex64 data")
+    if m == 0:
+        oshape = (n // nscrunch,) + tuple(x.shape[1:])
+    elif m == 1:
+        oshape = (n // nscrunch, nchan)
+    else:
+        oshape = (n // nscrunch, nchan, 4)
+    if isinstance(x, DeviceArray):
+        out = DeviceArray.empty(oshape, np.float32, device=x.device_index)
+        dev, stream = x.device_index, _stream_ptr(x.device_index)
+    else:
+        out = np.empty(oshape, dtype=np.float32)
+        dev, stream = 0, C.c_void_p(0)
+    pin, lin = _ptr_loc(x)
+    pout, lout = _ptr_loc(out)
+    _check(lib().pbh_detect(dev, stream, pin, pout, int(n), int(nchan), npol, m, int(nscrunch), lin, lout))
+    return out
+
+
+def fft_c2c(x, inverse=False):
+    """c2c FFT along axis 0 of an (n, ...) c64 array (numpy or DeviceArray), scipy norm=None."""
+    from .device import DeviceArray
+    _require_device()
+    if x.dtype != np.complex64:
+        raise TypeError("fft_c2c needs complex64 data")
+    n = x.shape[0]
+    batch = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
+    if isinstance(x, DeviceArray):
+        out = DeviceArray.empty(x.shape, np.complex64, device=x.device_index)
+        dev, stream = x.device_index, _stream_ptr(x.device_index)
+    else:
+        x = np.ascontiguousarray(x)
+        out = np.empty(x.shape, dtype=np.complex64)
+        dev, stream = 0, C.c_void_p(0)
+    pin, lin = _ptr_loc(x)
+    pout, lout = _ptr_loc(out)
+    _check(lib().pbh_fft_c2c(dev, stream, pin, pout, int(n), batch, int(bool(inverse)), lin, lout))
+    return out
+
+
+def chirp_function(coeff_hz, nsample, dt_s, center_freq_hz, ref_freq_hz, device=0, to_device=False):
+    """One channel's transfer function (nsample,) c64, generated by the HIP kernel."""
+    from .device import DeviceArray
+    _require_device()
+    if to_device:
+        out = DeviceArray.empty((int(nsample),), np.complex64, device=device)
+        stream = _stream_ptr(device)
+    else:
+        out = np.empty((int(nsample),), dtype=np.complex64)
+        stream = C.c_void_p(0)
+    ptr, loc = _ptr_loc(out)
+    _check(lib().pbh_chirp_function(int(device), stream, float(coeff_hz), int(nsample), float(dt_s),
+                                    float(center_freq_hz), float(ref_freq_hz), ptr, loc))
+    return out
+
+
+def copy_bench(nbytes, iters=10, device=0):
+    """Mean ms of a float4 device-to-device copy of ``nbytes`` (HBM yardstick)."""
+    _require_device()
+    ms = C.c_float()
+    _check(lib().pbh_copy_bench(int(device), int(nbytes), int(iters), C.byref(ms)))
+    return float(ms.value)

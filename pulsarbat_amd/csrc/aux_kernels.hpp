@@ -1,0 +1,159 @@
+// aux_kernels.hpp -- chirp generation, layout transposes, detection, streaming copy (gfx950).
+#pragma once
+#include "fft_core.hpp"
+
+namespace pbh {
+
+// ---- K1: chirp (transfer function) ----------------------------------------------------------------
+// Reproduces _transfer_function (pulsarbat/transforms/dedispersion.py:19-23) in float64:
+//   f   = chan_freq + fftfreq(N, dt)[k]          (numpy: integer bin * (1.0 / (N * dt)))
+//   phi = (coeff * f) * (1/ref - 1/f)^2          [cycles]
+//   out = complex64(exp(-2 pi i phi)) * scale
+// The phase reaches ~5e6 cycles at config 2 (1e8 at DM 1000), so phi is reduced to
+// phi - rint(phi) in float64 before sincospi.  Destination order:
+//   plan order  (n1 > 1): index chan*N + k1*N2 + k2 for bin k = k1 + N1*k2   (rows of the fused pass)
+//   natural order (n1 = 1, N2 = N): index chan*N + k
+struct ChirpParams {
+    cf* out;
+    const double* chan_freq;  // [nchan] device
+    double coeff, inv_ndt, inv_ref;
+    int64_t N;
+    int N1, N2, nchan;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
+    const int64_t total = p.N * p.nchan;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
+         d += (int64_t)gridDim.x * blockDim.x) {
+        const int chan = (int)(d / p.N);
+        const int64_t e = d - (int64_t)chan * p.N;
+        const int64_t k1 = e / p.N2, k2 = e - k1 * p.N2;
+        const int64_t k = k1 + (int64_t)p.N1 * k2;
+        const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
+        const double f = p.chan_freq[chan] + (double)bin * p.inv_ndt;
+        const double dd = p.inv_ref - 1.0 / f;
+        const double phi = (p.coeff * f) * (dd * dd);
+        const double fr = phi - rint(phi);
+        double sn, cs;
+        sincospi(2.0 * fr, &sn, &cs);
+        p.out[d] = make_float2((float)cs * p.scale, (float)(-sn) * p.scale);
+    }
+}
+
+// natural (N, nchan) <-> plan order [chan][k1][k2]; `to_plan` selects the direction.
+__global__ __launch_bounds__(256) void k_chirp_reorder(const cf* __restrict__ src, cf* __restrict__ dst,
+                                                       int64_t N, int N1, int N2, int nchan, float scale,
+                                                       int to_plan) {
+    const int64_t total = N * nchan;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
+         d += (int64_t)gridDim.x * blockDim.x) {
+        const int chan = (int)(d / N);
+        const int64_t e = d - (int64_t)chan * N;
+        const int64_t k1 = e / N2, k2 = e - k1 * N2;
+        const int64_t k = k1 + (int64_t)N1 * k2;
+        const int64_t nat = k * nchan + chan;
+        if (to_plan) {
+            cf a = src[nat];
+            dst[d] = make_float2(a.x * scale, a.y * scale);
+        } else {
+            cf a = src[d];
+            dst[nat] = make_float2(a.x * scale, a.y * scale);
+        }
+    }
+}
+
+// ---- layout transposes (PLANAR5 variant) -------------------------------------------------------------
+// (N, S) interleaved -> planar [s][n]; one workgroup moves a contiguous chunk of TN*S elements
+// through an LDS tile padded to S+1 per row so the transposed read is conflict-free.
+constexpr int kTrElems = 4096;
+
+__global__ __launch_bounds__(256) void k_deinterleave(const cf* __restrict__ in, cf* __restrict__ out,
+                                                      int64_t N, int S, int TN, int64_t plane) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, N - n0);
+    const int cnt = rows * S;
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        int n = e / S, s = e - n * S;
+        lds[n * (S + 1) + s] = in[n0 * S + e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        int s = e / rows, n = e - s * rows;
+        out[(int64_t)s * plane + n0 + n] = lds[n * (S + 1) + s];
+    }
+}
+
+// planar [s][t] -> (stop-start, S) interleaved, keeping t in [start, stop)
+__global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in, cf* __restrict__ out,
+                                                      int64_t start, int64_t stop, int S, int TN,
+                                                      int64_t plane) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int64_t t0 = start + (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, stop - t0);
+    const int cnt = rows * S;
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        int s = e / rows, n = e - s * rows;
+        lds[n * (S + 1) + s] = in[(int64_t)s * plane + t0 + n];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        int n = e / S, s = e - n * S;
+        out[(t0 - start) * S + e] = lds[n * (S + 1) + s];
+    }
+}
+
+// ---- detection (pulsarbat/core.py:766-774, 930-966), optional time scrunch -----------------------------
+// in: (n, nchan, npol) c64.  One thread per (output row, chan); sums nscrunch input rows in float32.
+__global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float* __restrict__ out,
+                                                int64_t nout, int nchan, int npol, int mode, int nscrunch) {
+    const int64_t total = nout * nchan;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
+         d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = d / nchan;
+        const int chan = (int)(d - o * nchan);
+        if (mode == 0) {
+            for (int pp = 0; pp < npol; ++pp) {
+                float acc = 0.f;
+                for (int j = 0; j < nscrunch; ++j) {
+                    cf a = in[((o * nscrunch + j) * nchan + chan) * npol + pp];
+                    acc += a.x * a.x + a.y * a.y;
+                }
+                out[d * npol + pp] = acc;
+            }
+        } else {
+            float si = 0.f, sq = 0.f, su = 0.f, sv = 0.f;
+            for (int j = 0; j < nscrunch; ++j) {
+                const cf* base = in + ((o * nscrunch + j) * nchan + chan) * 2;
+                cf a = base[0], b = base[1];
+                float aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
+                float re = a.x * b.x + a.y * b.y;  // Re(conj(a) b)
+                float im = a.x * b.y - a.y * b.x;  // Im(conj(a) b)
+                si += aa + bb;
+                if (mode == 2) {
+                    sq += aa - bb; su += 2.f * re; sv += 2.f * im;
+                } else if (mode == 3) {
+                    sq += 2.f * re; su += 2.f * im; sv += aa - bb;
+                }
+            }
+            if (mode == 1) {
+                out[d] = si;
+            } else {
+                float* o4 = out + d * 4;
+                o4[0] = si; o4[1] = sq; o4[2] = su; o4[3] = sv;
+            }
+        }
+    }
+}
+
+// ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+}  // namespace pbh

@@ -1,0 +1,692 @@
+// pbhip.hip -- host side of libpbhip.so: plans, launch sequences and the C ABI of include/pbhip.h.
+#include "../../include/pbhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.hpp"
+#include "kernels.hpp"
+
+using namespace pbh;
+
+// ---- error plumbing ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHECK(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(PBH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+#define PBHCHECK(expr)              \
+    do {                            \
+        int r_ = (expr);            \
+        if (r_ != PBH_OK) return r_; \
+    } while (0)
+
+static int ilog2(int64_t x) {
+    int l = 0;
+    while ((1LL << l) < x) ++l;
+    return l;
+}
+static bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// ---- plan ------------------------------------------------------------------------------------------------
+struct Step {
+    const char* name;
+    std::function<int(hipStream_t)> launch;
+};
+
+struct pbh_plan {
+    int device = 0;
+    int64_t N = 0, start = 0, stop = 0;
+    int nchan = 0, npol = 0, S = 0;
+    int N1 = 1, N2 = 1;
+    int variant = PBH_VARIANT_AUTO;
+    hipStream_t stream = nullptr;
+    bool has_chirp = false;
+
+    cf* work = nullptr;      // planar workspace, S * N
+    cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
+    cf* tw16k = nullptr;     // W_16384^p
+    double2* tw_hi = nullptr;
+    double2* tw_lo = nullptr;
+    int tw_shift = 0;
+    double* chan_freq = nullptr;
+    void* stage_in = nullptr;   // device staging for host inputs
+    void* stage_out = nullptr;  // device staging for host outputs
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    int64_t owned_bytes = 0;
+};
+
+static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess)
+        return fail(PBH_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    if (p) p->owned_bytes += (int64_t)bytes;
+    return PBH_OK;
+}
+
+static int resolved_variant(const pbh_plan* p) {
+    if (p->N1 == 1) return PBH_VARIANT_DIRECT3;  // single tile: no passes to choose
+    if (p->variant != PBH_VARIANT_AUTO) return p->variant;
+    return PBH_VARIANT_DIRECT3;
+}
+
+// ---- kernel dispatch by FFT length ---------------------------------------------------------------------------
+template <typename K, typename P>
+static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, bool pad, hipStream_t st) {
+    static thread_local const void* configured[64];
+    static thread_local int nconf = 0;
+    const size_t lds = pad ? lds_bytes<true>(kTilePoints) : lds_bytes<false>(kTilePoints);
+    bool seen = false;
+    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
+    if (!seen) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (nconf < 64) configured[nconf++] = (const void*)kernel;
+    }
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "tile count out of range");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(kThreads), lds, st, prm);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+#define FOR_ALL_M(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
+
+template <int OP>
+static int launch_col(int M, const ColParams& prm, hipStream_t st) {
+    const int F = kTilePoints / M;
+    const int64_t tiles = (prm.ncols + F - 1) / F;
+    switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP>, prm, tiles, (kTilePoints / m) < 16, st);
+        FOR_ALL_M(X)
+#undef X
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "column pass length " + std::to_string(M));
+}
+
+static int launch_row(int M, const RowParams& prm, hipStream_t st) {
+    const int FR = kTilePoints / M;
+    const int64_t tiles = (prm.nrows + FR - 1) / FR;
+    switch (M) {
+        case 2048: return launch_tile_kernel(k_row<2048>, prm, tiles, true, st);
+        case 4096: return launch_tile_kernel(k_row<4096>, prm, tiles, true, st);
+        case 8192: return launch_tile_kernel(k_row<8192>, prm, tiles, true, st);
+        case 16384: return launch_tile_kernel(k_row<16384>, prm, tiles, true, st);
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
+}
+
+static int launch_small(int M, const SmallParams& prm, hipStream_t st) {
+    const int F = kTilePoints / M;
+    const int64_t tiles = ((int64_t)prm.S + F - 1) / F;
+    switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_small<m>, prm, tiles, (kTilePoints / m) < 16, st);
+        FOR_ALL_M(X)
+#undef X
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "single-tile length " + std::to_string(M));
+}
+
+static int tr_rows(int S) {
+    int tn = kTrElems / S;
+    return tn < 1 ? 1 : tn;
+}
+
+// Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
+static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
+    std::vector<Step> steps;
+    const int S = p->S;
+    if (p->N1 == 1) {
+        SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, 1.0f};
+        const int M = (int)p->N;
+        steps.push_back({"k_small", [=](hipStream_t st) { return launch_small(M, sp, st); }});
+        return steps;
+    }
+    const int variant = resolved_variant(p);
+    BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, p->N - 1};
+    const int64_t ncols = (int64_t)S * p->N2;
+    ColSide planar{LAYOUT_PLANAR, p->N};
+    ColSide inter{LAYOUT_INTERLEAVED, 0};
+    const int N1 = p->N1, N2 = p->N2;
+    cf* work = p->work;
+
+    if (variant == PBH_VARIANT_PLANAR5) {
+        const int TN = tr_rows(S);
+        const size_t trlds = (size_t)TN * (S + 1) * sizeof(cf);
+        const int64_t N = p->N, start = p->start, stop = p->stop;
+        steps.push_back({"k_deinterleave", [=](hipStream_t st) {
+            hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256), trlds, st,
+                               in, work, N, S, TN, N);
+            HIPCHECK(hipGetLastError());
+            return (int)PBH_OK;
+        }});
+        ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, S, N2, ncols, tw, p->tw16k, 0, N, 0};
+        steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
+        steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
+        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, S, N2, ncols, tw, p->tw16k, 0, N, 0};
+        steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
+        steps.push_back({"k_reinterleave", [=](hipStream_t st) {
+            if (stop <= start) return (int)PBH_OK;
+            hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - start + TN - 1) / TN)), dim3(256),
+                               trlds, st, (const cf*)work, out, start, stop, S, TN, N);
+            HIPCHECK(hipGetLastError());
+            return (int)PBH_OK;
+        }});
+    } else {
+        ColParams c1{in, work, inter, planar, LAYOUT_INTERLEAVED, S, N2, ncols, tw, p->tw16k, 0, p->N, 0};
+        steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
+        steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
+        ColParams c3{work, out, planar, inter, LAYOUT_INTERLEAVED, S, N2, ncols, tw, p->tw16k,
+                     p->start, p->stop, p->start * S};
+        steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
+    }
+    return steps;
+}
+
+static int run_steps(std::vector<Step>& steps, hipStream_t st) {
+    for (auto& s : steps) PBHCHECK(s.launch(st));
+    return PBH_OK;
+}
+
+// ---- staging helpers ---------------------------------------------------------------------------------------
+static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
+    if (*have >= need) return PBH_OK;
+    if (*buf) {
+        hipFree(*buf);
+        p->owned_bytes -= (int64_t)*have;
+        *buf = nullptr;
+        *have = 0;
+    }
+    PBHCHECK(dev_alloc(p, buf, need));
+    *have = need;
+    return PBH_OK;
+}
+
+// ================================================ C ABI ==========================================================
+extern "C" {
+
+int pbh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pbh_last_error(void) { return g_err.c_str(); }
+
+const char* pbh_version(void) { return "pbhip 0.1.0 (gfx950)"; }
+
+int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
+                    int64_t crop_start, int64_t crop_stop) {
+    if (!out) return fail(PBH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
+    if (dtype != PBH_C64) return fail(PBH_ERR_UNSUPPORTED, "only complex64 is implemented");
+    if (!is_pow2(nsample) || nsample < 16 || nsample > (1LL << 28))
+        return fail(PBH_ERR_UNSUPPORTED,
+                    "nsample must be a power of two in [16, 2^28] (got " + std::to_string(nsample) + ")");
+    if (crop_start < 0 || crop_start > nsample) return fail(PBH_ERR_INVALID, "crop_start out of range");
+    if (crop_stop > nsample) return fail(PBH_ERR_INVALID, "crop_stop out of range");
+    int ndev = pbh_device_count();
+    if (device < 0 || device >= ndev)
+        return fail(PBH_ERR_INVALID, "device " + std::to_string(device) + " not present (" +
+                                         std::to_string(ndev) + " HIP devices)");
+    HIPCHECK(hipSetDevice(device));
+
+    pbh_plan* p = new pbh_plan();
+    p->device = device;
+    p->N = nsample;
+    p->nchan = nchan;
+    p->npol = npol;
+    p->S = nchan * npol;
+    p->start = crop_start;
+    p->stop = crop_stop < crop_start ? crop_start : crop_stop;  // empty result if the crop is negative
+    const int n = ilog2(nsample);
+    if (n <= kTileLog2) {
+        p->N1 = 1;
+        p->N2 = (int)nsample;
+    } else {
+        const int l2 = (n - 4 < kTileLog2) ? n - 4 : kTileLog2;
+        p->N2 = 1 << l2;
+        p->N1 = (int)(nsample >> l2);
+    }
+    int rc = PBH_OK;
+    auto bail = [&](int code) {
+        pbh_plan_destroy(p);
+        return code;
+    };
+    // stage twiddle table W_16384^p (float32 from float64 evaluation)
+    {
+        std::vector<cf> h(kTwTable);
+        for (int i = 0; i < kTwTable; ++i) {
+            double a = -2.0 * M_PI * (double)i / (double)kTwTable;
+            h[i] = make_float2((float)cos(a), (float)sin(a));
+        }
+        if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable)) != PBH_OK) return bail(rc);
+        if (hipMemcpy(p->tw16k, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(PBH_ERR_HIP, "hipMemcpy(tw16k) failed"));
+    }
+    if ((rc = dev_alloc(p, (void**)&p->chirp, sizeof(cf) * (size_t)nchan * nsample)) != PBH_OK) return bail(rc);
+    if ((rc = dev_alloc(p, (void**)&p->chan_freq, sizeof(double) * nchan)) != PBH_OK) return bail(rc);
+    if (p->N1 > 1) {
+        // W_N^p = hi[p >> shift] * lo[p & mask], float64
+        p->tw_shift = (n + 1) / 2;
+        const int64_t nlo = 1LL << p->tw_shift, nhi = nsample >> p->tw_shift;
+        std::vector<double2> lo(nlo), hi(nhi);
+        for (int64_t i = 0; i < nlo; ++i) {
+            double a = -2.0 * M_PI * (double)i / (double)nsample;
+            lo[i] = make_double2(cos(a), sin(a));
+        }
+        for (int64_t i = 0; i < nhi; ++i) {
+            double a = -2.0 * M_PI * (double)(i << p->tw_shift) / (double)nsample;
+            hi[i] = make_double2(cos(a), sin(a));
+        }
+        if ((rc = dev_alloc(p, (void**)&p->tw_lo, sizeof(double2) * nlo)) != PBH_OK) return bail(rc);
+        if ((rc = dev_alloc(p, (void**)&p->tw_hi, sizeof(double2) * nhi)) != PBH_OK) return bail(rc);
+        if (hipMemcpy(p->tw_lo, lo.data(), sizeof(double2) * nlo, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->tw_hi, hi.data(), sizeof(double2) * nhi, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(PBH_ERR_HIP, "hipMemcpy(twiddle tables) failed"));
+        if ((rc = dev_alloc(p, (void**)&p->work, sizeof(cf) * (size_t)p->S * nsample)) != PBH_OK) return bail(rc);
+    }
+    *out = p;
+    return PBH_OK;
+}
+
+int pbh_plan_destroy(pbh_plan* p) {
+    if (!p) return PBH_OK;
+    hipSetDevice(p->device);
+    void* ptrs[] = {p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    delete p;
+    return PBH_OK;
+}
+
+int pbh_plan_set_stream(pbh_plan* p, void* hip_stream) {
+    if (!p) return fail(PBH_ERR_INVALID, "plan is NULL");
+    p->stream = (hipStream_t)hip_stream;
+    return PBH_OK;
+}
+
+int pbh_plan_set_variant(pbh_plan* p, int variant) {
+    if (!p) return fail(PBH_ERR_INVALID, "plan is NULL");
+    if (variant < PBH_VARIANT_AUTO || variant > PBH_VARIANT_DIRECT3) return fail(PBH_ERR_INVALID, "bad variant");
+    p->variant = variant;
+    return PBH_OK;
+}
+
+int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
+    if (!p || !info) return fail(PBH_ERR_INVALID, "NULL argument");
+    info->nsample = p->N;
+    info->crop_start = p->start;
+    info->crop_stop = p->stop;
+    info->nchan = p->nchan;
+    info->npol = p->npol;
+    info->device = p->device;
+    info->n1 = p->N1;
+    info->n2 = p->N2;
+    info->variant = resolved_variant(p);
+    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3);
+    info->workspace_bytes = p->owned_bytes;
+    // 4 passes * 16 B + chirp 8/npol B for multi-pass transforms; one read + one write
+    // + chirp for a transform that fits one tile.
+    info->alg_bytes_per_sample = (p->N1 == 1 ? 16.0 : 64.0) + 8.0 / p->npol;
+    return PBH_OK;
+}
+
+// ---- chirp --------------------------------------------------------------------------------------------------
+static float inv_n(const pbh_plan* p) { return (float)(1.0 / (double)p->N); }
+
+int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* chan_freq_hz, double ref_freq_hz) {
+    if (!p || !chan_freq_hz) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!(dt_s > 0)) return fail(PBH_ERR_INVALID, "dt must be positive");
+    HIPCHECK(hipSetDevice(p->device));
+    HIPCHECK(hipMemcpyAsync(p->chan_freq, chan_freq_hz, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
+    ChirpParams cp{p->chirp, p->chan_freq, coeff_hz, 1.0 / ((double)p->N * dt_s), 1.0 / ref_freq_hz,
+                   p->N, p->N1, p->N2, p->nchan, inv_n(p)};
+    hipLaunchKernelGGL(k_chirp, dim3(2048), dim3(256), 0, p->stream, cp);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(p->stream));  // chan_freq_hz is a borrowed host buffer
+    p->has_chirp = true;
+    return PBH_OK;
+}
+
+int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
+    if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    HIPCHECK(hipSetDevice(p->device));
+    const size_t bytes = sizeof(cf) * (size_t)p->nchan * p->N;
+    const cf* src = (const cf*)chirp_c64;
+    if (loc == PBH_HOST) {
+        PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, bytes));
+        HIPCHECK(hipMemcpyAsync(p->stage_in, chirp_c64, bytes, hipMemcpyHostToDevice, p->stream));
+        src = (const cf*)p->stage_in;
+    }
+    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, p->chirp, p->N, p->N1, p->N2,
+                       p->nchan, inv_n(p), 1);
+    HIPCHECK(hipGetLastError());
+    if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
+    p->has_chirp = true;
+    return PBH_OK;
+}
+
+int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
+    if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "plan has no chirp yet");
+    HIPCHECK(hipSetDevice(p->device));
+    const size_t bytes = sizeof(cf) * (size_t)p->nchan * p->N;
+    cf* dst = (cf*)chirp_c64;
+    if (loc == PBH_HOST) {
+        PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, bytes));
+        dst = (cf*)p->stage_out;
+    }
+    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const cf*)p->chirp, dst, p->N, p->N1,
+                       p->N2, p->nchan, (float)p->N, 0);
+    HIPCHECK(hipGetLastError());
+    if (loc == PBH_HOST) {
+        HIPCHECK(hipMemcpyAsync(chirp_c64, dst, bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHECK(hipStreamSynchronize(p->stream));
+    }
+    return PBH_OK;
+}
+
+int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t nsample, double dt_s,
+                       double center_freq_hz, double ref_freq_hz, void* chirp_c64, int loc) {
+    if (!chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || nsample > (1LL << 30) || !(dt_s > 0)) return fail(PBH_ERR_INVALID, "bad nsample/dt");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t bytes = sizeof(cf) * (size_t)nsample;
+    double* dfreq = nullptr;
+    cf* dbuf = (cf*)chirp_c64;
+    PBHCHECK(dev_alloc(nullptr, (void**)&dfreq, sizeof(double)));
+    int rc = PBH_OK;
+    if (loc == PBH_HOST && (rc = dev_alloc(nullptr, (void**)&dbuf, bytes)) != PBH_OK) {
+        hipFree(dfreq);
+        return rc;
+    }
+    auto cleanup = [&]() {
+        hipFree(dfreq);
+        if (loc == PBH_HOST) hipFree(dbuf);
+    };
+    hipError_t e = hipMemcpyAsync(dfreq, &center_freq_hz, sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        // natural order, any nsample (not only powers of two): N1 = 1, N2 = N
+        ChirpParams cp{dbuf, dfreq, coeff_hz, 1.0 / ((double)nsample * dt_s), 1.0 / ref_freq_hz,
+                       nsample, 1, (int)nsample, 1, 1.0f};
+        hipLaunchKernelGGL(k_chirp, dim3(1024), dim3(256), 0, st, cp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && loc == PBH_HOST) e = hipMemcpyAsync(chirp_c64, dbuf, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_chirp_function: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+// ---- hot path --------------------------------------------------------------------------------------------------
+static int resolve_io(pbh_plan* p, const void* in, void* out, size_t out_bytes, int in_loc, int out_loc,
+                      const cf** din, void** dout) {
+    const size_t in_bytes = sizeof(cf) * (size_t)p->S * p->N;
+    *din = (const cf*)in;
+    *dout = out;
+    if (in_loc == PBH_HOST) {
+        PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, in_bytes));
+        HIPCHECK(hipMemcpyAsync(p->stage_in, in, in_bytes, hipMemcpyHostToDevice, p->stream));
+        *din = (const cf*)p->stage_in;
+    }
+    if (out_loc == PBH_HOST) {
+        PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, out_bytes ? out_bytes : 16));
+        *dout = p->stage_out;
+    }
+    return PBH_OK;
+}
+
+int pbh_dedisperse(pbh_plan* p, const void* in_c64, void* out_c64, int in_loc, int out_loc) {
+    if (!p || !in_c64 || !out_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    HIPCHECK(hipSetDevice(p->device));
+    const size_t out_bytes = sizeof(cf) * (size_t)p->S * (size_t)(p->stop - p->start);
+    const cf* din;
+    void* dout;
+    PBHCHECK(resolve_io(p, in_c64, out_c64, out_bytes, in_loc, out_loc, &din, &dout));
+    if (p->stop > p->start) {
+        auto steps = build_steps(p, din, (cf*)dout);
+        PBHCHECK(run_steps(steps, p->stream));
+    }
+    if (out_loc == PBH_HOST && out_bytes)
+        HIPCHECK(hipMemcpyAsync(out_c64, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
+    return PBH_OK;
+}
+
+static int detect_out_elems(int mode, int npol) {
+    switch (mode) {
+        case PBH_DETECT_INTENSITY: return npol;
+        case PBH_DETECT_STOKES_I: return 1;
+        case PBH_DETECT_STOKES_LINEAR:
+        case PBH_DETECT_STOKES_CIRCULAR: return 4;
+    }
+    return 0;
+}
+
+static int launch_detect(hipStream_t st, const cf* in, float* out, int64_t nout, int nchan, int npol, int mode,
+                         int nscrunch) {
+    if (nout <= 0) return PBH_OK;
+    int64_t blocks = (nout * nchan + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_detect, dim3((unsigned)blocks), dim3(256), 0, st, in, out, nout, nchan, npol, mode, nscrunch);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, int64_t nsample, int nchan,
+               int npol, int mode, int nscrunch, int in_loc, int out_loc) {
+    if (!in_c64 || !out_f32) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || nchan <= 0 || npol <= 0 || nscrunch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    const int oe = detect_out_elems(mode, npol);
+    if (!oe) return fail(PBH_ERR_INVALID, "bad detect mode");
+    if (mode != PBH_DETECT_INTENSITY && npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int64_t nout = nsample / nscrunch;
+    const size_t in_bytes = sizeof(cf) * (size_t)nsample * nchan * npol;
+    const size_t out_bytes = sizeof(float) * (size_t)nout * nchan * oe;
+    const cf* din = (const cf*)in_c64;
+    float* dout = (float*)out_f32;
+    void *sin = nullptr, *sout = nullptr;
+    int rc = PBH_OK;
+    if (in_loc == PBH_HOST) {
+        if ((rc = dev_alloc(nullptr, &sin, in_bytes)) != PBH_OK) return rc;
+        hipMemcpyAsync(sin, in_c64, in_bytes, hipMemcpyHostToDevice, st);
+        din = (const cf*)sin;
+    }
+    if (out_loc == PBH_HOST) {
+        if ((rc = dev_alloc(nullptr, &sout, out_bytes ? out_bytes : 16)) != PBH_OK) {
+            if (sin) hipFree(sin);
+            return rc;
+        }
+        dout = (float*)sout;
+    }
+    rc = launch_detect(st, din, dout, nout, nchan, npol, mode, nscrunch);
+    hipError_t e = hipSuccess;
+    if (rc == PBH_OK && out_loc == PBH_HOST && out_bytes)
+        e = hipMemcpyAsync(out_f32, dout, out_bytes, hipMemcpyDeviceToHost, st);
+    if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e2;
+    }
+    if (sin) hipFree(sin);
+    if (sout) hipFree(sout);
+    if (rc != PBH_OK) return rc;
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_detect: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int nscrunch, int mode, int in_loc,
+                          int out_loc) {
+    if (!p || !in_c64 || !out_f32) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nscrunch <= 0) return fail(PBH_ERR_INVALID, "nscrunch must be positive");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    const int oe = detect_out_elems(mode, p->npol);
+    if (!oe) return fail(PBH_ERR_INVALID, "bad detect mode");
+    if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
+    HIPCHECK(hipSetDevice(p->device));
+    const int64_t nvalid = p->stop - p->start;
+    const int64_t nout = nvalid / nscrunch;
+    const size_t out_bytes = sizeof(float) * (size_t)nout * p->nchan * oe;
+    const size_t mid_bytes = sizeof(cf) * (size_t)p->S * (size_t)nvalid;
+    const cf* din;
+    void* dout;
+    PBHCHECK(resolve_io(p, in_c64, out_f32, out_bytes, in_loc, out_loc, &din, &dout));
+    if (nout > 0) {
+        // round-1 form: dedisperse into a device buffer, then detect+scrunch (fused tail: see DESIGN.md)
+        void* mid = nullptr;
+        PBHCHECK(dev_alloc(nullptr, &mid, mid_bytes));
+        auto steps = build_steps(p, din, (cf*)mid);
+        int rc = run_steps(steps, p->stream);
+        if (rc == PBH_OK)
+            rc = launch_detect(p->stream, (const cf*)mid, (float*)dout, nout, p->nchan, p->npol, mode, nscrunch);
+        hipStreamSynchronize(p->stream);
+        hipFree(mid);
+        PBHCHECK(rc);
+    }
+    if (out_loc == PBH_HOST && out_bytes)
+        HIPCHECK(hipMemcpyAsync(out_f32, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
+    return PBH_OK;
+}
+
+int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64, int64_t n, int64_t batch,
+                int inverse, int in_loc, int out_loc) {
+    if (!in_c64 || !out_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (n <= 0 || batch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    if (!is_pow2(n) || n < 16 || n > kTilePoints)
+        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [16, 16384] in this build");
+    if (batch > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "batch too large");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    static thread_local cf* tw = nullptr;
+    static thread_local int tw_dev = -1;
+    if (!tw || tw_dev != device) {
+        std::vector<cf> h(kTwTable);
+        for (int i = 0; i < kTwTable; ++i) {
+            double a = -2.0 * M_PI * (double)i / (double)kTwTable;
+            h[i] = make_float2((float)cos(a), (float)sin(a));
+        }
+        PBHCHECK(dev_alloc(nullptr, (void**)&tw, sizeof(cf) * kTwTable));
+        HIPCHECK(hipMemcpy(tw, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice));
+        tw_dev = device;
+    }
+    const size_t bytes = sizeof(cf) * (size_t)n * batch;
+    const cf* din = (const cf*)in_c64;
+    cf* dout = (cf*)out_c64;
+    void *sin = nullptr, *sout = nullptr;
+    int rc = PBH_OK;
+    if (in_loc == PBH_HOST) {
+        PBHCHECK(dev_alloc(nullptr, &sin, bytes));
+        hipMemcpyAsync(sin, in_c64, bytes, hipMemcpyHostToDevice, st);
+        din = (const cf*)sin;
+    }
+    if (out_loc == PBH_HOST) {
+        if ((rc = dev_alloc(nullptr, &sout, bytes)) != PBH_OK) {
+            if (sin) hipFree(sin);
+            return rc;
+        }
+        dout = (cf*)sout;
+    }
+    SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (float)(1.0 / (double)n)};
+    rc = launch_small((int)n, sp, st);
+    hipError_t e = hipSuccess;
+    if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out_c64, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e2;
+    }
+    if (sin) hipFree(sin);
+    if (sout) hipFree(sout);
+    if (rc != PBH_OK) return rc;
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_fft_c2c: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------------
+int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, float* ms_per_kernel, int* nkernel,
+                     const char** names) {
+    if (!p || !in_dev || !out_dev || !ms_per_kernel || !nkernel) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp");
+    if (iters <= 0) return fail(PBH_ERR_INVALID, "iters must be positive");
+    HIPCHECK(hipSetDevice(p->device));
+    auto steps = build_steps(p, (const cf*)in_dev, (cf*)out_dev);
+    const int nk = (int)steps.size();
+    if (nk > PBH_MAX_KERNELS) return fail(PBH_ERR_INVALID, "too many kernels");
+    std::vector<hipEvent_t> ev(nk + 1);
+    for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
+    std::vector<double> acc(nk, 0.0);
+    int rc = PBH_OK;
+    for (int it = 0; it < iters && rc == PBH_OK; ++it) {
+        hipEventRecord(ev[0], p->stream);
+        for (int k = 0; k < nk && rc == PBH_OK; ++k) {
+            rc = steps[k].launch(p->stream);
+            hipEventRecord(ev[k + 1], p->stream);
+        }
+        if (hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(PBH_ERR_HIP, "profile: stream sync failed");
+        for (int k = 0; k < nk && rc == PBH_OK; ++k) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            acc[k] += ms;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    PBHCHECK(rc);
+    for (int k = 0; k < nk; ++k) {
+        ms_per_kernel[k] = (float)(acc[k] / iters);
+        if (names) names[k] = steps[k].name;
+    }
+    *nkernel = nk;
+    return PBH_OK;
+}
+
+int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
+    if (!ms_mean || bytes < 16 || iters <= 0) return fail(PBH_ERR_INVALID, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    void *a = nullptr, *b = nullptr;
+    PBHCHECK(dev_alloc(nullptr, &a, (size_t)bytes));
+    if (dev_alloc(nullptr, &b, (size_t)bytes) != PBH_OK) {
+        hipFree(a);
+        return PBH_ERR_NOMEM;
+    }
+    hipMemset(a, 1, (size_t)bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int64_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+    hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(a);
+    hipFree(b);
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("copy bench: ") + hipGetErrorString(e));
+    *ms_mean = ms / iters;
+    return PBH_OK;
+}
+
+}  // extern "C"

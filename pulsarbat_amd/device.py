@@ -1,0 +1,117 @@
+"""HBM-resident array that can sit in ``Signal.data``.
+
+The reference's ``Signal`` touches only ``ndim/shape/dtype/astype/__len__/
+__getitem__`` of its data plus ``numpy.asanyarray`` for host copies
+(pulsarbat/core.py:59-97, 149-153, 207-230): the same seam its dask arrays use.
+``DeviceArray`` implements that protocol over a torch ROCm tensor (torch is
+used for device memory and streams only).  Keeping a signal's data as a
+DeviceArray is this build's ``persist()``; ``numpy.asarray(x)`` / ``x.get()`` is
+its ``compute()``.
+"""
+
+import numpy as np
+
+__all__ = ["DeviceArray"]
+
+_NP2T = None
+
+
+def _maps():
+    global _NP2T
+    if _NP2T is None:
+        import torch
+        _NP2T = {np.dtype(np.complex64): torch.complex64, np.dtype(np.float32): torch.float32,
+                 np.dtype(np.complex128): torch.complex128, np.dtype(np.float64): torch.float64}
+    return _NP2T
+
+
+class DeviceArray:
+    __array_priority__ = 100
+
+    def __init__(self, tensor):
+        import torch
+        if not isinstance(tensor, torch.Tensor) or not tensor.is_cuda:
+            raise TypeError("DeviceArray wraps a torch tensor living on a HIP device")
+        self._t = tensor
+
+    # --- construction -------------------------------------------------------------
+    @classmethod
+    def empty(cls, shape, dtype, device=None):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        return cls(torch.empty(tuple(int(s) for s in shape), dtype=_maps()[np.dtype(dtype)], device=dev))
+
+    @classmethod
+    def from_host(cls, a, device=None):
+        import torch
+        if isinstance(a, DeviceArray):
+            return a
+        a = np.ascontiguousarray(a)
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        return cls(torch.from_numpy(a).to(dev))
+
+    # --- array protocol used by Signal ---------------------------------------------------
+    @property
+    def tensor(self):
+        return self._t
+
+    @property
+    def device_index(self):
+        return self._t.device.index
+
+    @property
+    def shape(self):
+        return tuple(self._t.shape)
+
+    @property
+    def ndim(self):
+        return self._t.dim()
+
+    @property
+    def dtype(self):
+        for npd, td in _maps().items():
+            if td == self._t.dtype:
+                return npd
+        raise TypeError(f"unsupported tensor dtype {self._t.dtype}")
+
+    @property
+    def size(self):
+        return self._t.numel()
+
+    @property
+    def nbytes(self):
+        return self._t.numel() * self._t.element_size()
+
+    def __len__(self):
+        return self._t.shape[0]
+
+    def __getitem__(self, index):
+        return DeviceArray(self._t[index])
+
+    def astype(self, dtype, casting="unsafe", copy=True):
+        dtype = np.dtype(dtype)
+        if not np.can_cast(self.dtype, dtype, casting=casting):
+            raise TypeError(f"Cannot cast array data from {self.dtype} to {dtype} according to the rule '{casting}'")
+        if dtype == self.dtype and not copy:
+            return self
+        return DeviceArray(self._t.to(_maps()[dtype]))
+
+    def data_ptr(self):
+        """Device pointer of a C-contiguous view (what the C ABI takes)."""
+        if not self._t.is_contiguous():
+            raise ValueError("the C ABI needs a C-contiguous device array; call .contiguous() first")
+        return self._t.data_ptr()
+
+    def contiguous(self):
+        return self if self._t.is_contiguous() else DeviceArray(self._t.contiguous())
+
+    def get(self):
+        """Host copy as numpy."""
+        return self._t.cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __repr__(self):
+        return f"DeviceArray<shape={self.shape}, dtype={self.dtype}, device={self._t.device}>"

@@ -1,0 +1,223 @@
+"""Dedispersion: the hot path's host side (reference pulsarbat/transforms/dedispersion.py).
+
+Everything numeric happens in libpbhip.so (HIP kernels); this module keeps the
+reference's call surface -- ``DispersionMeasure`` (``time_delay``, ``sample_delay``,
+``chirp_function``, ``chirp_from_signal``) and ``coherent_dedispersion(z, DM, /, *,
+ref_freq=None, chirp=None)`` -- its type checks, crop arithmetic
+(dedispersion.py:127-131) and ``start_time`` bookkeeping (core.py:155-164).
+The device boundary sits at dedispersion.py:125 (``ifft(fft(x) * chirp)``) and
+dedispersion.py:19-23 (``_transfer_function``).  There is no CPU fallback.
+"""
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _hip
+from .. import units as u
+from ..core import BasebandSignal
+from ..device import DeviceArray
+
+__all__ = [
+    "DispersionMeasure",
+    "DM",
+    "coherent_dedispersion",
+    "dedisperse_detect",
+]
+
+_DM_UNIT = u.pc / u.cm ** 3
+_DM_UNIT.name = "pc / cm3"
+
+
+def _hz(q):
+    """Frequency as float Hz; ``numpy.inf`` passes through (tests/test_dedispersion.py:17-21)."""
+    if isinstance(q, (int, float)) and math.isinf(q):
+        return float(q)
+    return u.to_value(q, u.Hz)
+
+
+class DispersionMeasure(u.Quantity):
+    """Dispersion measure, default unit pc / cm^3 (dedispersion.py:26-30)."""
+
+    __slots__ = ()
+    # dedispersion.py:30: s MHz^2 cm^3 / pc / 2.41e-4
+    dispersion_constant = u.Quantity(1.0 / 2.41e-4, u.s * u.MHz ** 2 * u.cm ** 3 / u.pc)
+
+    def __init__(self, value, unit=None):
+        if isinstance(value, u.Quantity) and unit is None:
+            value, unit = value.to_value(_DM_UNIT), _DM_UNIT
+        unit = _DM_UNIT if unit is None else unit
+        if not u._as_unit(unit).is_equivalent(_DM_UNIT):
+            raise u.UnitConversionError("DispersionMeasure needs units equivalent to pc / cm^3")
+        super().__init__(value, unit)
+
+    @property
+    def _coeff_s_mhz2(self):
+        """dispersion_constant * DM in s MHz^2 (dedispersion.py:34, 46)."""
+        return self.to_value(_DM_UNIT) / 2.41e-4
+
+    def time_delay(self, f, ref_freq):
+        """Delay of ``f`` relative to ``ref_freq``: D*DM*(1/f^2 - 1/ref^2) (dedispersion.py:32-36)."""
+        f_mhz = np.asarray(_hz(f), dtype=float) / 1e6
+        r_mhz = np.asarray(_hz(ref_freq), dtype=float) / 1e6
+        with np.errstate(divide="ignore"):
+            d = self._coeff_s_mhz2 * (1.0 / f_mhz ** 2 - 1.0 / r_mhz ** 2)
+        return u.Quantity(d if d.ndim else float(d), u.s)
+
+    def sample_delay(self, f, ref_freq, sample_rate):
+        """time_delay * sample_rate as plain floats (dedispersion.py:38-42)."""
+        return self.time_delay(f, ref_freq).to_value(u.s) * _hz(sample_rate)
+
+    def chirp_function(self, N, dt, center_freq, ref_freq, use_dask=False, *, device=None):
+        """Transfer function of one channel, complex64 ``(N,)`` (dedispersion.py:44-57).
+
+        Computed by the HIP chirp kernel (float64 phase).  ``use_dask`` is accepted for
+        signature parity and ignored; ``device=<index>`` returns a DeviceArray instead of
+        a host array.
+        """
+        return _hip.chirp_function(
+            self._coeff_s_mhz2 * 1e12, int(N), u.to_value(dt, u.s), _hz(center_freq), _hz(ref_freq),
+            device=0 if device is None else device, to_device=device is not None)
+
+    def chirp_from_signal(self, z, /, *, ref_freq=None):
+        """Chirp ``(N, nchan, 1, ...)`` that dedisperses ``z`` (dedispersion.py:59-75).
+
+        Host-resident signals get a numpy array, device-resident ones a DeviceArray.
+        """
+        if not isinstance(z, BasebandSignal):
+            raise TypeError("Signal must be a BasebandSignal object.")
+        if ref_freq is None:
+            ref_freq = z.center_freq
+        plan, on_device = _plan_for(z, self, ref_freq, crop=(0, len(z)))
+        shape = (len(z), z.nchan) + (1,) * (z.ndim - 2)
+        if on_device:
+            out = DeviceArray.empty((len(z), z.nchan), np.complex64, device=plan.device)
+            plan.chirp_download(out)
+            return DeviceArray(out.tensor.reshape(shape))
+        return plan.chirp_download().reshape(shape)
+
+    chirp = chirp_from_signal  # BASELINE.json north_star spells it `.chirp`
+
+
+DM = DispersionMeasure
+
+# ---- plan cache --------------------------------------------------------------------------------
+_PLANS = OrderedDict()
+_PLAN_CACHE_SIZE = 4
+
+
+def _device_of(z):
+    return z.data.device_index if isinstance(z.data, DeviceArray) else 0
+
+
+def _geometry(z):
+    nchan = z.shape[1]
+    npol = int(np.prod(z.shape[2:])) if z.ndim > 2 else 1
+    return len(z), nchan, npol
+
+
+def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
+    """Cached pbh plan for this signal geometry (+ generated chirp)."""
+    nsample, nchan, npol = _geometry(z)
+    dev = _device_of(z)
+    freqs = np.asarray(u.to_value(z.channel_freqs, u.Hz), dtype=np.float64).reshape(nchan)
+    coeff = dm._coeff_s_mhz2 * 1e12
+    dt = u.to_value(z.dt, u.s)
+    ref = _hz(ref_freq)
+    ckey = None if chirp is not None else (coeff, dt, freqs.tobytes(), ref)
+    key = (nsample, nchan, npol, crop, dev, variant)
+    ent = _PLANS.pop(key, None)
+    if ent is None:
+        plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant)
+        ent = [plan, object()]
+    plan = ent[0]
+    if chirp is not None:
+        plan.chirp_upload(chirp)
+        ent[1] = object()
+    elif ent[1] != ckey:
+        plan.chirp_generate(coeff, dt, freqs, ref)
+        ent[1] = ckey
+    _PLANS[key] = ent
+    while len(_PLANS) > _PLAN_CACHE_SIZE:
+        _, old = _PLANS.popitem(last=False)
+        old[0].close()
+    return plan, isinstance(z.data, DeviceArray)
+
+
+def clear_plan_cache():
+    while _PLANS:
+        _, ent = _PLANS.popitem()
+        ent[0].close()
+
+
+def _crop_bounds(z, dm, ref_freq):
+    """start/stop of dedispersion.py:127-131."""
+    delay_top = float(dm.sample_delay(z.max_freq, ref_freq, z.sample_rate))
+    delay_bot = float(dm.sample_delay(z.min_freq, ref_freq, z.sample_rate))
+    start = math.ceil(-min(0, delay_top, delay_bot))
+    stop = len(z) - math.ceil(+max(0, delay_top, delay_bot))
+    return start, stop
+
+
+def _as_2d_chirp(chirp, z):
+    """A user chirp is (N, nchan) or (N, nchan, 1, ...) (dedispersion.py:103-105, 124)."""
+    want = (len(z), z.nchan)
+    shape = tuple(chirp.shape)
+    if shape[:2] != want or any(s != 1 for s in shape[2:]):
+        raise NotImplementedError(
+            f"chirp must have shape {want} (optionally with trailing length-1 axes); got {shape}")
+    if isinstance(chirp, DeviceArray):
+        c = DeviceArray(chirp.tensor.reshape(want)).contiguous()
+        return c if c.dtype == np.complex64 else c.astype(np.complex64)
+    return np.ascontiguousarray(np.asarray(chirp).reshape(want), dtype=np.complex64)
+
+
+def _prepare(z, DM, ref_freq, chirp, variant):
+    if not isinstance(z, BasebandSignal):
+        raise TypeError("Signal must be a BasebandSignal object.")
+    if ref_freq is None:
+        ref_freq = z.center_freq
+    if z.dtype != np.complex64:
+        raise NotImplementedError(
+            "the HIP path computes in complex64 (float32), like scipy.fft on complex64 input; "
+            f"got {z.dtype}. Cast with z.data.astype(numpy.complex64) first.")
+    start, stop = _crop_bounds(z, DM, ref_freq)
+    c2 = None if chirp is None else _as_2d_chirp(chirp, z)
+    plan, on_device = _plan_for(z, DM, ref_freq, (start, stop), chirp=c2, variant=variant)
+    x = z.data.contiguous() if on_device else np.ascontiguousarray(z.data)
+    return plan, x, start, stop
+
+
+def _advance(z, start):
+    if z.start_time is None:
+        return {}
+    return {"start_time": z.start_time + start / z.sample_rate}
+
+
+def coherent_dedispersion(z, DM, /, *, ref_freq=None, chirp=None, variant="auto"):
+    """Coherently dedisperse a baseband signal (dedispersion.py:81-133).
+
+    ``z`` must be a BasebandSignal with complex64 data, host (numpy) or device
+    (DeviceArray); the result keeps the container type.  ``ref_freq`` defaults to the
+    signal's centre frequency.  A pre-computed ``chirp`` (shape ``z.shape[:2]``) is used
+    unchecked, as in the reference.  The output is cropped to ``[start, stop)`` to drop
+    wrap-around, and ``start_time`` advances by ``start / sample_rate``.  ``variant`` is a
+    build-specific knob selecting the kernel sequence ("auto", "direct3", "planar5").
+    """
+    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant)
+    y = plan.dedisperse(x)
+    return type(z).like(z, y, **_advance(z, start))
+
+
+def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch=1, variant="auto"):
+    """coherent_dedispersion followed by detection and an ``nscrunch``-fold time sum.
+
+    Equivalent to ``coherent_dedispersion(z, DM).to_intensity()`` (mode "intensity":
+    core.py:766-774) or ``.to_stokes()`` (mode "linear"/"circular": core.py:930-966; "I":
+    Stokes I only), then ``a[:n*k].reshape(n, k, ...).sum(1)``.  The reference has no
+    scrunch function; SURVEY.md 8a row 9 defines it.  Returns a float32 array (numpy or
+    DeviceArray) and the crop start, not a Signal, since the sample rate changes.
+    """
+    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant)
+    return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
