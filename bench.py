@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the coherent-dedispersion hot path on MI355X.
+
+Metric (BASELINE.json): complex Msamples/s dedispersed, where one sample is one complex64
+element of the input (nsample, nchan, npol) block (samples later cropped are counted), with
+the HBM roofline of the dominant kernel beside it.
+
+Workload: BASELINE.json configs[1] at N=1: 2^24 samples x 8 chan x 2 pol complex64, DM 56.77,
+400 MHz at 1.4 GHz.  At N>1 the same 400 MHz band is cut into 8*N channels (N=8 is
+configs[2]: 64 channels of 6.25 MHz); every rank holds 8 channels x 2 pol x 2^24 samples of
+it, so per-GPU work is fixed ("weak").  Channels are independent, so there is no data-path
+collective: ranks only meet at the timing barriers.
+
+One "step" = one pbh_dedisperse call (FFT -> chirp -> IFFT -> crop) on a block already
+resident in HBM, output left resident.  Chirp generation is a per-geometry setup cost and is
+timed separately (reported as chirp_ms).
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu]
+  N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+            --master-port P bench.py --gpus N --steps K --warmup W
+"""
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
+NSAMPLE = 1 << 24
+NCHAN_PER_GPU = 8
+NPOL = 2
+DM = 56.77
+BAND_HZ = 400e6
+CENTER_HZ = 1.4e9
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline():
+    """Oracle (numpy + scipy.fft restatement of the reference) on a bounded sample.
+
+    Sample: (2^22, 8, 2) complex64 = 1/4 of the workload's time axis with the same channel
+    layout, chirp precomputed, scipy.fft workers=None (one thread: what the reference runs,
+    pulsarbat/fft.py:36-38).  A second figure uses all host cores (not reference behaviour).
+    """
+    from oracle import dedisp_oracle as orc
+    n = 1 << 22
+    shape = (n, NCHAN_PER_GPU, NPOL)
+    x = orc.synthetic_block(shape, 20260002)
+    sr = BAND_HZ / NCHAN_PER_GPU
+    t0 = time.perf_counter()
+    chirp = orc.chirp_from_signal(DM, shape, sr, CENTER_HZ)
+    t_chirp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.coherent_dedispersion(x, DM, sr, CENTER_HZ, chirp=chirp)
+    t1 = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    orc.coherent_dedispersion(x, DM, sr, CENTER_HZ, chirp=chirp, workers=ncores)
+    tall = time.perf_counter() - t0
+    nsamp = float(np.prod(shape))
+    return {
+        "value": nsamp / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": "oracle (numpy+scipy.fft, workers=None) on one (2^22, 8, 2) c64 block, "
+                  "DM 56.77, chirp precomputed; %.2f s" % t1,
+        "all_cores": {"value": nsamp / tall / 1e6, "cores": ncores, "seconds": tall},
+        "chirp_seconds": t_chirp, "host_cpus": ncores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--variant", default="auto")
+    ap.add_argument("--log2n", type=int, default=24, help="(debug) nsample = 2^log2n")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
+            sys.exit(2)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pulsarbat_amd import _hip
+    from pulsarbat_amd.device import DeviceArray
+    import pulsarbat_amd as pb
+    from pulsarbat_amd import units as u
+
+    nsample = 1 << args.log2n
+    nchan_total = NCHAN_PER_GPU * world
+    sr = BAND_HZ / nchan_total
+    # geometry through the product's own host code (RadioSignal.channel_freqs / crop rule)
+    freqs_all = CENTER_HZ + sr * (np.arange(nchan_total) + 0.5 - nchan_total / 2)
+    freqs = freqs_all[rank * NCHAN_PER_GPU:(rank + 1) * NCHAN_PER_GPU]
+    dm = pb.DM(DM)
+    d_top = dm.sample_delay((CENTER_HZ + BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    d_bot = dm.sample_delay((CENTER_HZ - BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    start = math.ceil(-min(0, d_top, d_bot))
+    stop = nsample - math.ceil(max(0, d_top, d_bot))
+    coeff = DM / 2.41e-4 * 1e12
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20260002 + rank)
+    x = torch.randn((nsample, NCHAN_PER_GPU, NPOL, 2), generator=gen, device="cuda",
+                    dtype=torch.float32) * (2 ** -0.5)
+    x = DeviceArray(torch.view_as_complex(x))
+    plan = _hip.Plan(nsample, NCHAN_PER_GPU, NPOL, start, stop, device=local_rank, variant=args.variant)
+    y = DeviceArray.empty((plan.nout, NCHAN_PER_GPU, NPOL), np.complex64, device=local_rank)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.chirp_generate(coeff, 1.0 / sr, freqs, CENTER_HZ)
+    torch.cuda.synchronize()
+    chirp_ms = (time.perf_counter() - t0) * 1e3
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.dedisperse(x, out=y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.dedisperse(x, out=y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event timing on the plan's stream (same launches as the timed region)
+    kern = plan.profile(x, y, iters=max(3, min(args.steps, 10)))
+    info = plan.info
+    samples_gpu = float(nsample) * NCHAN_PER_GPU * NPOL
+    # algorithmic bytes per sample of each kernel (DESIGN.md "Kernels"): reads + writes it cannot avoid
+    crop_frac = plan.nout / nsample
+    alg = {"k_col_fwd": 16.0, "k_row_fused": 16.0 + 8.0 / NPOL, "k_col_inv": 8.0 + 8.0 * crop_frac,
+           "k_deinterleave": 16.0, "k_reinterleave": 16.0 * crop_frac, "k_small": 8.0 + 8.0 * crop_frac + 8.0 / NPOL}
+    dom_name, dom_ms = max(kern, key=lambda kv: kv[1])
+    dom_bytes = alg[dom_name] * samples_gpu
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "alg_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms}
+    total_kernel_ms = sum(ms for _, ms in kern)
+    path_bytes = info["alg_bytes_per_sample"] * samples_gpu  # 68 B/sample accounting figure
+    path = {"alg_bytes_per_sample": info["alg_bytes_per_sample"],
+            "achieved": path_bytes / (total_kernel_ms * 1e-3) / 1e9, "unit": "GB/s",
+            "frac": path_bytes / (total_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "kernel_ms": {k: round(v, 4) for k, v in kern}, "kernel_ms_total": total_kernel_ms}
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = samples_gpu * world * args.steps / elapsed / 1e6
+        result = {
+            "metric": "complex Msamples/s dedispersed (2^24x8chx2pol c64); HBM GB/s vs peak",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "c64", "data": "synthetic",
+            "config": {"workload": "configs[1]: 2^%d samples x 8 chan x 2 pol complex64 per GPU, DM=56.77, "
+                                   "400 MHz band @ 1.4 GHz split into %d channels; device-resident in/out"
+                                   % (args.log2n, nchan_total),
+                       "nsample": nsample, "nchan_per_gpu": NCHAN_PER_GPU, "npol": NPOL,
+                       "nchan_total": nchan_total, "crop": [start, stop], "variant": info["variant"],
+                       "n1": info["n1"], "n2": info["n2"], "sharding": "channels across ranks, no collective"},
+            "roofline": roofline, "path_roofline": path, "chirp_ms": chirp_ms,
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:  # the baseline is a reported extra; never lose the GPU line
+                result["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,12 +1,15 @@
 // fft_core.hpp -- register-resident tile FFT for gfx950 (wave64, 160 KiB LDS / CU).
 //
-// A workgroup of 1024 threads owns a TILE of 2^14 complex64 points = F independent FFTs of
-// length M (F * M = 2^14).  Every thread keeps R = 16 points in VGPRs; a Stockham radix-16
-// stage is one in-register 16-point DFT per thread, and LDS is only the exchange medium
-// between stages (write scattered, read unit-stride).  The Stockham index algebra makes the
-// thread <-> point distribution identical before the first and after the last stage
-// (thread tau holds positions tau + i*M/16, i = 0..15, in natural order), so a forward
-// transform, a pointwise multiply and an inverse transform chain with no extra shuffles.
+// A workgroup owns a TILE of 2^14 complex64 points = F independent FFTs of length M
+// (F * M = 2^14).  Every thread keeps R points (R = 16 or 32) in VGPRs; a Stockham stage is
+// one in-register radix-R DFT per thread, and LDS is only the exchange medium between stages
+// (write scattered, read unit-stride).  The Stockham index algebra makes the thread <-> point
+// distribution identical before the first and after the last stage (thread tau holds
+// positions tau + i*M/R, i = 0..R-1, in natural order), so a forward transform, a pointwise
+// multiply and an inverse transform chain with no extra shuffles.
+//
+// R = 32 with 512 threads gives each thread a 256-VGPR budget (no spills) and turns a 2^14
+// transform into 32 x 32 x 16: two LDS exchanges instead of three.
 //
 // No reference counterpart: the reference delegates to scipy.fft (pocketfft) via
 // pulsarbat/fft.py:36-38; this is the from-scratch replacement of that call for c64.
@@ -20,8 +23,6 @@ typedef float2 cf;
 
 constexpr int kTileLog2 = 14;
 constexpr int kTilePoints = 1 << kTileLog2;  // complex points per workgroup tile
-constexpr int kR = 16;                       // points per thread
-constexpr int kThreads = kTilePoints / kR;   // 1024
 constexpr int kTwTable = 1 << 14;            // stage twiddle table: W_16384^p (forward sign)
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -37,35 +38,32 @@ __device__ __forceinline__ cf mul_i(cf a) {
     return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
 
-// Multiply by W_16^p (forward: exp(-2 pi i p/16); inverse: conjugate).  p is a compile-time
+// Multiply by W_32^p (forward: exp(-2 pi i p/32); inverse: conjugate).  p is a compile-time
 // constant after unrolling, so the branches fold away.
 template <int DIR>
-__device__ __forceinline__ cf mul_w16(cf a, int p) {
-    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-    p &= 15;
-    if (p == 0) return a;
-    if (p == 4) return mul_i<DIR>(a);
-    if (p == 8) return make_float2(-a.x, -a.y);
-    if (p == 12) return mul_i<-DIR>(a);
-    float c, s;  // cos / sin of 2 pi p / 16
-    switch (p) {
-        case 1: c = c1; s = s1; break;
-        case 2: c = h; s = h; break;
-        case 3: c = s1; s = c1; break;
-        case 5: c = -s1; s = c1; break;
-        case 6: c = -h; s = h; break;
-        case 7: c = -c1; s = s1; break;
-        case 9: c = -c1; s = -s1; break;
-        case 10: c = -h; s = -h; break;
-        case 11: c = -s1; s = -c1; break;
-        case 13: c = s1; s = -c1; break;
-        case 14: c = h; s = -h; break;
-        default: c = c1; s = -s1; break;  // 15
+__device__ __forceinline__ cf mul_w32(cf a, int p) {
+    p &= 31;
+    const int quad = p >> 3, r = p & 7;
+    if (r != 0) {
+        float c, s;
+        switch (r) {
+            case 1: c = 0.98078528040323043f; s = 0.19509032201612825f; break;
+            case 2: c = 0.92387953251128674f; s = 0.38268343236508977f; break;
+            case 3: c = 0.83146961230254524f; s = 0.55557023301960218f; break;
+            case 4: c = 0.70710678118654752f; s = 0.70710678118654752f; break;
+            case 5: c = 0.55557023301960218f; s = 0.83146961230254524f; break;
+            case 6: c = 0.38268343236508977f; s = 0.92387953251128674f; break;
+            default: c = 0.19509032201612825f; s = 0.98078528040323043f; break;
+        }
+        a = cmul(a, make_float2(c, DIR < 0 ? -s : s));
     }
-    return cmul(a, make_float2(c, DIR < 0 ? -s : s));
+    if (quad == 1) return mul_i<DIR>(a);
+    if (quad == 2) return make_float2(-a.x, -a.y);
+    if (quad == 3) return mul_i<-DIR>(a);
+    return a;
 }
 
-// ---- in-register DFTs of size 1, 2, 4, 8, 16 (natural-order output) -------------------------
+// ---- in-register DFTs of size 1..32 (natural-order output) --------------------------------------
 template <int R, int DIR>
 struct Dft;
 
@@ -105,7 +103,7 @@ __device__ __forceinline__ void dft_composite(cf (&v)[R1 * R2]) {
         for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
         Dft<R1, DIR>::run(t);
 #pragma unroll
-        for (int k1 = 0; k1 < R1; ++k1) a[n2][k1] = mul_w16<DIR>(t[k1], n2 * k1 * (16 / R));
+        for (int k1 = 0; k1 < R1; ++k1) a[n2][k1] = mul_w32<DIR>(t[k1], n2 * k1 * (32 / R));
     }
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
@@ -125,49 +123,64 @@ template <int DIR>
 struct Dft<16, DIR> {
     static __device__ __forceinline__ void run(cf (&v)[16]) { dft_composite<4, 4, DIR>(v); }
 };
+template <int DIR>
+struct Dft<32, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[32]) { dft_composite<4, 8, DIR>(v); }
+};
 
 // ---- stage plan ------------------------------------------------------------------------------
-// Stages for length M: radix 16 while at least 16 remain, then one stage of the remainder.
-constexpr int stage_radix(int M, int NS) { return (M / NS >= 16) ? 16 : (M / NS); }
+// Stages for length M with R points per thread: radix R while at least R remain, then one
+// stage of the remainder.
+constexpr int stage_radix(int M, int NS, int R) { return (M / NS >= R) ? R : (M / NS); }
 // number of stage-twiddle seeds a thread needs for the stages starting at sub-length NS
-constexpr int tw_seeds(int M, int NS) {
+constexpr int tw_seeds(int M, int NS, int R) {
     return NS >= M ? 0
-                   : ((NS > 1 ? 16 / stage_radix(M, NS) : 0) + tw_seeds(M, NS * stage_radix(M, NS)));
+                   : ((NS > 1 ? R / stage_radix(M, NS, R) : 0) +
+                      tw_seeds(M, NS * stage_radix(M, NS, R), R));
 }
-constexpr int tw_seeds_or1(int M) { return tw_seeds(M, 1) > 0 ? tw_seeds(M, 1) : 1; }
+constexpr int tw_seeds_or1(int M, int R) { return tw_seeds(M, 1, R) > 0 ? tw_seeds(M, 1, R) : 1; }
 
-// LDS addressing of a tile: logical slot L = pos * PS + fofs, optionally padded by one slot
-// every 16 to break power-of-two strides (ds_write_b64 lane groups are 16 lanes wide).
+// LDS addressing of a tile.  Logical slot L = pos * PS + fofs (8-byte slots).
+//   PAD = false: identity (column tiles with >= 16 interleaved FFTs are conflict-free as is)
+//   PAD = true : one pad slot per 32, phys = L + (L >> 5).  A radix-R stage writes with lane
+//                stride R slots; the pad turns that into stride R+1 (conflict-free across a
+//                16-lane ds_write_b64 group), and unit-stride reads of 32 lanes stay 32
+//                consecutive slots.  The map is linear (phys(L0 + d) = phys(L0) + d + (d >> 5)
+//                when the low 5 bits do not carry), so every access is base VGPR + immediate.
 template <bool PAD>
-__device__ __forceinline__ int lds_slot(int L) {
-    return PAD ? L + (L >> 4) : L;
+__device__ __forceinline__ int lds_phys(int L) {
+    return PAD ? L + (L >> 5) : L;
 }
 template <bool PAD>
-constexpr int lds_bytes(int points) {
-    return (PAD ? points + (points >> 4) : points) * (int)sizeof(cf);
+constexpr int lds_lin(int d) {
+    return PAD ? d + (d >> 5) : d;
+}
+template <bool PAD>
+constexpr int lds_tile_bytes() {
+    return (PAD ? kTilePoints + (kTilePoints >> 5) : kTilePoints) * (int)sizeof(float2);
 }
 
 // Load the per-stage twiddle seeds W_{NS*RAD}^{k} for this thread (global table, L2-resident).
-template <int M, int NS>
+template <int M, int NS, int R>
 __device__ __forceinline__ void load_tw_seeds(cf* w, int tau, const cf* __restrict__ tw) {
     if constexpr (NS < M) {
-        constexpr int RAD = stage_radix(M, NS);
-        constexpr int NB = 16 / RAD;
+        constexpr int RAD = stage_radix(M, NS, R);
+        constexpr int NB = R / RAD;
         if constexpr (NS > 1) {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                int jb = tau + q * (M / 16);
+                int jb = tau + q * (M / R);
                 int k = jb & (NS - 1);
                 w[q] = tw[k * (kTwTable / (NS * RAD))];
             }
-            load_tw_seeds<M, NS * RAD>(w + NB, tau, tw);
+            load_tw_seeds<M, NS * RAD, R>(w + NB, tau, tw);
         } else {
-            load_tw_seeds<M, NS * RAD>(w, tau, tw);
+            load_tw_seeds<M, NS * RAD, R>(w, tau, tw);
         }
     }
 }
 
-// t[j] *= w^j, j = 1..RAD-1, powers by a depth<=4 product tree (w2=w^2, w3=w2*w, w4=w2^2, ...)
+// t[j] *= w^j, j = 1..RAD-1, powers by a product tree of depth <= 5
 template <int RAD>
 __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
     if constexpr (RAD >= 2) t[1] = cmul(t[1], w1);
@@ -184,37 +197,48 @@ __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
             t[6] = cmul(t[6], w6);
             t[7] = cmul(t[7], w7);
             if constexpr (RAD >= 16) {
-                cf w8 = csqr(w4);
-                t[8] = cmul(t[8], w8);
-                t[9] = cmul(t[9], cmul(w8, w1));
-                t[10] = cmul(t[10], csqr(w5));
-                t[11] = cmul(t[11], cmul(w8, w3));
-                t[12] = cmul(t[12], csqr(w6));
-                t[13] = cmul(t[13], cmul(w8, w5));
-                t[14] = cmul(t[14], csqr(w7));
-                t[15] = cmul(t[15], cmul(w8, w7));
+                cf p[16];  // w^8 .. w^15 in p[8..15]; w^1..w^7 reused below for RAD = 32
+                p[1] = w1; p[2] = w2; p[3] = w3; p[4] = w4; p[5] = w5; p[6] = w6; p[7] = w7;
+                p[8] = csqr(w4);
+                p[9] = cmul(p[8], w1);
+                p[10] = csqr(w5);
+                p[11] = cmul(p[8], w3);
+                p[12] = csqr(w6);
+                p[13] = cmul(p[8], w5);
+                p[14] = csqr(w7);
+                p[15] = cmul(p[8], w7);
+#pragma unroll
+                for (int j = 8; j < 16; ++j) t[j] = cmul(t[j], p[j]);
+                if constexpr (RAD >= 32) {
+                    cf w16 = csqr(p[8]);
+                    t[16] = cmul(t[16], w16);
+#pragma unroll
+                    for (int j = 1; j < 16; ++j) t[16 + j] = cmul(t[16 + j], cmul(w16, p[j]));
+                }
             }
         }
     }
 }
 
-// One tile FFT of length M on the 16 points of each thread.
-//   v[i]  : position tau + i*M/16 of this thread's FFT, natural order, in and out
-//   lds   : tile exchange buffer; slot(pos) = lds_slot<PAD>(pos * PS + fofs)
-//   w     : seeds from load_tw_seeds<M, 1> (forward sign; conjugated here for DIR = +1)
+// One tile FFT of length M on the R points of each thread.
+//   v[i]  : position tau + i*M/R of this thread's FFT, natural order, in and out
+//   lds   : tile exchange buffer; slot(pos) = lds_phys<PAD>(pos * PS + fofs)
+//   w     : seeds from load_tw_seeds<M, 1, R> (forward sign; conjugated here for DIR = +1)
+// fofs must be a multiple of 32 when PS == 1 (row tiles: fofs = f * M).
 // Must be called by all threads of the workgroup (contains barriers).
-template <int M, int NS, int DIR, int PS, bool PAD>
-__device__ __forceinline__ void fft_tile(cf (&v)[16], cf* lds, int tau, int fofs, const cf* w) {
+template <int M, int NS, int R, int DIR, int PS, bool PAD>
+__device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w) {
     if constexpr (NS < M) {
-        constexpr int RAD = stage_radix(M, NS);
-        constexpr int NB = 16 / RAD;
+        constexpr int RAD = stage_radix(M, NS, R);
+        constexpr int NB = R / RAD;
+        constexpr int MR = M / R;
         constexpr bool LAST = (NS * RAD == M);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             cf t[RAD];
 #pragma unroll
             for (int j = 0; j < RAD; ++j) t[j] = v[q + j * NB];
-            int jb = tau + q * (M / 16);
+            int jb = tau + q * MR;
             int k = jb & (NS - 1);
             if constexpr (NS > 1) {
                 cf w1 = w[q];
@@ -226,19 +250,52 @@ __device__ __forceinline__ void fft_tile(cf (&v)[16], cf* lds, int tau, int fofs
 #pragma unroll
                 for (int u = 0; u < RAD; ++u) v[q + u * NB] = t[u];
             } else {
-                int base = (jb - k) * RAD + k;
+                const int base = (jb - k) * RAD + k;
+                // linear form is exact when the step is a multiple of 32 slots, or when it is the
+                // first stage of a row tile (base*PS+fofs is a multiple of RAD, u < RAD <= 32)
+                constexpr bool LIN = !PAD || ((NS * PS) % 32 == 0) || (NS == 1 && PS == 1 && RAD == 32);
+                if constexpr (LIN) {
+                    cf* wp = lds + lds_phys<PAD>(base * PS + fofs);
 #pragma unroll
-                for (int u = 0; u < RAD; ++u) lds[lds_slot<PAD>((base + u * NS) * PS + fofs)] = t[u];
+                    for (int u = 0; u < RAD; ++u) wp[lds_lin<PAD>(u * NS * PS)] = t[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RAD; ++u) lds[lds_phys<PAD>((base + u * NS) * PS + fofs)] = t[u];
+                }
             }
         }
         if constexpr (!LAST) {
             __syncthreads();
+            constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
+            if constexpr (RLIN) {
+                const cf* rp = lds + lds_phys<PAD>(tau * PS + fofs);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = lds[lds_slot<PAD>((tau + i * (M / 16)) * PS + fofs)];
+                for (int i = 0; i < R; ++i) v[i] = rp[lds_lin<PAD>(i * MR * PS)];
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) v[i] = lds[lds_phys<PAD>((tau + i * MR) * PS + fofs)];
+            }
             __syncthreads();
-            fft_tile<M, NS * RAD, DIR, PS, PAD>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
         }
     }
+}
+
+// ---- buffer (SRD) addressing: wave-uniform base in SGPRs, 32-bit per-lane offset, scalar step ----
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
+    u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
+    u32x2 x;
+    x.x = __float_as_uint(a.x);
+    x.y = __float_as_uint(a.y);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 
 // ---- float64 inter-pass twiddles W_N^p via a two-level table ------------------------------------

@@ -47,10 +47,11 @@ __device__ __forceinline__ int64_t col_addr(const ColSide& sd, int64_t row, int 
                                            : (int64_t)s * sd.plane + row * N2 + n2;
 }
 
-template <int M, int OP>
-__global__ __launch_bounds__(kThreads) void k_col(ColParams p) {
+template <int M, int OP, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_col(ColParams p) {
     constexpr int F = kTilePoints / M;  // columns per tile
     constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;           // row stride between a thread's points
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
 
@@ -69,41 +70,41 @@ __global__ __launch_bounds__(kThreads) void k_col(ColParams p) {
         }
     }
 
-    cf w[tw_seeds_or1(M)];
-    load_tw_seeds<M, 1>(w, tau, p.tw16k);
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
-    cf v[16];
+    cf v[R];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int row = tau + i * (M / 16);
+    for (int i = 0; i < R; ++i) {
+        int row = tau + i * MR;
         v[i] = valid ? p.in[col_addr(p.is, row, n2, s, p.S, p.N2)] : make_float2(0.f, 0.f);
     }
 
-    // inter-pass twiddle W_N^{n2 * k1}, k1 = tau + i*M/16: base * step^i, float64 recurrence
+    // inter-pass twiddle W_N^{n2 * k1}, k1 = tau + i*M/R: base * step^i, float64 recurrence
     double2 zb = big_tw(p.tw, (int64_t)n2 * tau);
-    double2 zs = big_tw(p.tw, (int64_t)n2 * (M / 16));
+    double2 zs = big_tw(p.tw, (int64_t)n2 * MR);
 
     if constexpr (OP == OP_TW_INV) {
         double2 z = zb;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < R; ++i) {
             v[i] = cmul(v[i], make_float2((float)z.x, (float)-z.y));
             z = zmul(z, zs);
         }
-        fft_tile<M, 1, +1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int row = tau + i * (M / 16);
+        for (int i = 0; i < R; ++i) {
+            int row = tau + i * MR;
             int64_t t = (int64_t)row * p.N2 + n2;
             if (valid && t >= p.crop_start && t < p.crop_stop)
                 p.out[col_addr(p.os, row, n2, s, p.S, p.N2) - p.out_shift] = v[i];
         }
     } else {
-        fft_tile<M, 1, -1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
         double2 z = zb;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int row = tau + i * (M / 16);
+        for (int i = 0; i < R; ++i) {
+            int row = tau + i * MR;
             cf r = cmul(v[i], make_float2((float)z.x, (float)z.y));
             z = zmul(z, zs);
             if (valid) p.out[col_addr(p.os, row, n2, s, p.S, p.N2)] = r;
@@ -120,38 +121,41 @@ struct RowParams {
     int N1, npol;
 };
 
-template <int M>
-__global__ __launch_bounds__(kThreads) void k_row(RowParams p) {
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     constexpr int FR = kTilePoints / M;  // rows per tile
+    constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
 
     const int tid = threadIdx.x;
-    const int tau = tid % (M / 16), f = tid / (M / 16);
-    const int64_t r = (int64_t)blockIdx.x * FR + f;
-    const bool valid = r < p.nrows;
-    const int64_t rr = valid ? r : 0;
-    const int64_t srs = rr / p.N1;  // series
-    const int k1 = (int)(rr % p.N1);
-    cf* row = p.data + rr * M;
-    const cf* crow = p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M;
+    const int tau = tid % MR, f = tid / MR;
+    // tile = FR consecutive rows (same series: FR divides N1); rows past nrows are masked by
+    // the descriptor's byte count (loads return 0, stores are dropped)
+    const int64_t r0 = (int64_t)blockIdx.x * FR;
+    const int64_t left = p.nrows - r0;
+    const uint32_t bytes = (uint32_t)((left < FR ? left : FR) * (int64_t)M * sizeof(cf));
+    const int64_t srs = r0 / p.N1;
+    const int k1 = (int)(r0 % p.N1);
+    const rsrc_t rd = make_rsrc(p.data + r0 * M, bytes);
+    const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M, bytes);
+    const int voff = (f * M + tau) * (int)sizeof(cf);
+    constexpr int STEP = MR * (int)sizeof(cf);
 
-    cf w[tw_seeds_or1(M)];
-    load_tw_seeds<M, 1>(w, tau, p.tw16k);
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
-    cf v[16];
+    cf v[R];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = valid ? row[tau + i * (M / 16)] : make_float2(0.f, 0.f);
+    for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
 
-    fft_tile<M, 1, -1, 1, true>(v, lds, tau, f * M, w);
+    fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = cmul(v[i], crow[tau + i * (M / 16)]);
-    fft_tile<M, 1, +1, 1, true>(v, lds, tau, f * M, w);
+    for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, voff, i * STEP));
+    fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
 
-    if (valid) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) row[tau + i * (M / 16)] = v[i];
-    }
+    for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
 }
 
 // ---- single-tile transform (nsample = M <= 2^14) -------------------------------------------------------
@@ -166,10 +170,11 @@ struct SmallParams {
     float scale;  // plain-FFT mode only
 };
 
-template <int M>
-__global__ __launch_bounds__(kThreads) void k_small(SmallParams p) {
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     constexpr int F = kTilePoints / M;
     constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
 
@@ -179,31 +184,31 @@ __global__ __launch_bounds__(kThreads) void k_small(SmallParams p) {
     const bool valid = q < p.S;
     const int64_t qq = valid ? q : 0;
 
-    cf w[tw_seeds_or1(M)];
-    load_tw_seeds<M, 1>(w, tau, p.tw16k);
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
-    cf v[16];
+    cf v[R];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int64_t row = tau + i * (M / 16);
+    for (int i = 0; i < R; ++i) {
+        int64_t row = tau + i * MR;
         v[i] = valid ? p.in[row * p.S + qq] : make_float2(0.f, 0.f);
     }
     if (p.chirp) {
         const cf* crow = p.chirp + (qq / p.npol) * (int64_t)M;
-        fft_tile<M, 1, -1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = cmul(v[i], crow[tau + i * (M / 16)]);
-        fft_tile<M, 1, +1, F, PAD>(v, lds, tau, f, w);
+        for (int i = 0; i < R; ++i) v[i] = cmul(v[i], crow[tau + i * MR]);
+        fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
     } else if (p.dir < 0) {
-        fft_tile<M, 1, -1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
     } else {
-        fft_tile<M, 1, +1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = make_float2(v[i].x * p.scale, v[i].y * p.scale);
+        for (int i = 0; i < R; ++i) v[i] = make_float2(v[i].x * p.scale, v[i].y * p.scale);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int64_t row = tau + i * (M / 16);
+    for (int i = 0; i < R; ++i) {
+        int64_t row = tau + i * MR;
         if (valid && row >= p.crop_start && row < p.crop_stop)
             p.out[(row - p.crop_start) * p.S + qq] = v[i];
     }

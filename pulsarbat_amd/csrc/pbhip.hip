@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -84,31 +85,47 @@ static int resolved_variant(const pbh_plan* p) {
 }
 
 // ---- kernel dispatch by FFT length ---------------------------------------------------------------------------
+static int col_points_per_thread() {
+    static int r = [] {
+        const char* e = getenv("PBH_COL_R");
+        int v = e ? atoi(e) : 32;
+        return (v == 16) ? 16 : 32;
+    }();
+    return r;
+}
+
 template <typename K, typename P>
-static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, bool pad, hipStream_t st) {
-    static thread_local const void* configured[64];
+static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads, hipStream_t st) {
+    static thread_local const void* configured[128];
     static thread_local int nconf = 0;
-    const size_t lds = pad ? lds_bytes<true>(kTilePoints) : lds_bytes<false>(kTilePoints);
+    const size_t lds = lds_tile_bytes<true>();  // 132 KiB: the tile plus one pad slot per 32
     bool seen = false;
     for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
     if (!seen) {
         HIPCHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (nconf < 64) configured[nconf++] = (const void*)kernel;
+        if (nconf < 128) configured[nconf++] = (const void*)kernel;
     }
     if (tiles <= 0 || tiles > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "tile count out of range");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(kThreads), lds, st, prm);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(threads), lds, st, prm);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
 
-#define FOR_ALL_M(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
+#define FOR_ALL_M(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
 
 template <int OP>
 static int launch_col(int M, const ColParams& prm, hipStream_t st) {
     const int F = kTilePoints / M;
     const int64_t tiles = (prm.ncols + F - 1) / F;
+    if (col_points_per_thread() == 16) {
+        switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 16>, prm, tiles, kTilePoints / 16, st);
+            FOR_ALL_M(X)
+#undef X
+        }
+    }
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP>, prm, tiles, (kTilePoints / m) < 16, st);
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32>, prm, tiles, kTilePoints / 32, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -119,10 +136,9 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     const int64_t tiles = (prm.nrows + FR - 1) / FR;
     switch (M) {
-        case 2048: return launch_tile_kernel(k_row<2048>, prm, tiles, true, st);
-        case 4096: return launch_tile_kernel(k_row<4096>, prm, tiles, true, st);
-        case 8192: return launch_tile_kernel(k_row<8192>, prm, tiles, true, st);
-        case 16384: return launch_tile_kernel(k_row<16384>, prm, tiles, true, st);
+#define X(m) case m: return launch_tile_kernel(k_row<m, 32>, prm, tiles, kTilePoints / 32, st);
+        X(1024) X(2048) X(4096) X(8192) X(16384)
+#undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
 }
@@ -131,7 +147,7 @@ static int launch_small(int M, const SmallParams& prm, hipStream_t st) {
     const int F = kTilePoints / M;
     const int64_t tiles = ((int64_t)prm.S + F - 1) / F;
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_small<m>, prm, tiles, (kTilePoints / m) < 16, st);
+#define X(m) case m: return launch_tile_kernel(k_small<m, 32>, prm, tiles, kTilePoints / 32, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -234,9 +250,9 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
     *out = nullptr;
     if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
     if (dtype != PBH_C64) return fail(PBH_ERR_UNSUPPORTED, "only complex64 is implemented");
-    if (!is_pow2(nsample) || nsample < 16 || nsample > (1LL << 28))
+    if (!is_pow2(nsample) || nsample < 32 || nsample > (1LL << 28))
         return fail(PBH_ERR_UNSUPPORTED,
-                    "nsample must be a power of two in [16, 2^28] (got " + std::to_string(nsample) + ")");
+                    "nsample must be a power of two in [32, 2^28] (got " + std::to_string(nsample) + ")");
     if (crop_start < 0 || crop_start > nsample) return fail(PBH_ERR_INVALID, "crop_start out of range");
     if (crop_stop > nsample) return fail(PBH_ERR_INVALID, "crop_stop out of range");
     int ndev = pbh_device_count();
@@ -258,7 +274,7 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
         p->N1 = 1;
         p->N2 = (int)nsample;
     } else {
-        const int l2 = (n - 4 < kTileLog2) ? n - 4 : kTileLog2;
+        const int l2 = (n - 5 < kTileLog2) ? n - 5 : kTileLog2;
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
     }
@@ -572,8 +588,8 @@ int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64,
                 int inverse, int in_loc, int out_loc) {
     if (!in_c64 || !out_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     if (n <= 0 || batch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
-    if (!is_pow2(n) || n < 16 || n > kTilePoints)
-        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [16, 16384] in this build");
+    if (!is_pow2(n) || n < 32 || n > kTilePoints)
+        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [32, 16384] in this build");
     if (batch > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "batch too large");
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;

@@ -34,7 +34,7 @@ if __name__ == "__main__":
         c = pb.DM(56.77).chirp_function(N, (1 / 50e6) * u.s, 1225e6 * u.Hz, 1.4e9 * u.Hz)
         cr = orc.transfer_function(56.77, N, 1 / 50e6, 1225e6, 1.4e9)
         print("chirp", N, "max abs err", float(np.abs(c - cr).max()), flush=True)
-    for n in (16, 64, 1024, 4096, 8192, 16384):
+    for n in (32, 64, 1024, 4096, 8192, 16384):
         ok &= check((n, 4, 2), 10.0 if n >= 4096 else 0.01, 1e6, 1e9)
     for n in (15, 16, 18, 19, 20):
         for variant in ("direct3", "planar5"):
