@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--log2n", type=int, default=24, help="(debug) nsample = 2^log2n")
+    ap.add_argument("--dm", type=float, default=DM, help="(debug) dispersion measure")
     args = ap.parse_args()
 
     import torch
@@ -113,12 +114,12 @@ def main():
     # geometry through the product's own host code (RadioSignal.channel_freqs / crop rule)
     freqs_all = CENTER_HZ + sr * (np.arange(nchan_total) + 0.5 - nchan_total / 2)
     freqs = freqs_all[rank * NCHAN_PER_GPU:(rank + 1) * NCHAN_PER_GPU]
-    dm = pb.DM(DM)
+    dm = pb.DM(args.dm)
     d_top = dm.sample_delay((CENTER_HZ + BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
     d_bot = dm.sample_delay((CENTER_HZ - BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
     start = math.ceil(-min(0, d_top, d_bot))
     stop = nsample - math.ceil(max(0, d_top, d_bot))
-    coeff = DM / 2.41e-4 * 1e12
+    coeff = args.dm / 2.41e-4 * 1e12
 
     gen = torch.Generator(device="cuda")
     gen.manual_seed(20260002 + rank)

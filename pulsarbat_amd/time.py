@@ -38,10 +38,10 @@ class Time:
             if val2 is not None:
                 sec += float(val2) * 86400.0
         elif format == "isot":
-            d = _dt.datetime.fromisoformat(str(val).rstrip("Z"))
-            frac = 0.0
-            if "." in str(val):
-                frac = float("0." + str(val).rstrip("Z").split(".")[1])
+            txt = str(val).rstrip("Z")
+            whole, _, fracdigits = txt.partition(".")
+            d = _dt.datetime.fromisoformat(whole)
+            frac = float("0." + fracdigits) if fracdigits else 0.0
             day = d.date().toordinal() - _dt.date(1970, 1, 1).toordinal() + _MJD_UNIX_EPOCH
             sec = d.hour * 3600 + d.minute * 60 + d.second + frac
         elif format == "unix":

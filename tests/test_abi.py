@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/pbhip.h declares (no compute calls)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pbhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbh_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_declares_the_hot_path():
+    names = declared_symbols()
+    for must in ("pbh_plan_create", "pbh_plan_destroy", "pbh_chirp_generate", "pbh_chirp_upload",
+                 "pbh_dedisperse", "pbh_dedisperse_detect", "pbh_fft_c2c", "pbh_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from pulsarbat_amd import _build, _hip
+    assert os.path.exists(_build.LIB), "libpbhip.so missing: run __graft_entry__.build()"
+    lib = _hip.lib()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in pbhip.h but not exported"
+        assert name in _hip.SIGNATURES, f"{name} has no ctypes signature"
+    assert b"pbhip" in lib.pbh_version()
+
+
+def test_argument_validation_without_gpu():
+    """Error codes and messages for bad arguments (these paths return before touching HIP)."""
+    from pulsarbat_amd import _hip
+    lib = _hip.lib()
+    h = ctypes.c_void_p()
+    assert lib.pbh_plan_create(None, 0, 1024, 1, 1, 0, 0, 1024) == -1
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1000, 1, 1, 0, 0, 1000) == -2
+    assert b"power of two" in lib.pbh_last_error()
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 0, 1, 0, 0, 1024) == -1
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 7, 0, 1024) == -2
+    assert lib.pbh_plan_destroy(None) == 0
+    assert lib.pbh_dedisperse(None, None, None, 0, 0) == -1
+    assert lib.pbh_fft_c2c(0, None, None, None, 1024, 1, 0, 0, 0) == -1
+    if lib.pbh_device_count() == 0:
+        assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 0, 0, 1024) == -1
+        assert b"not present" in lib.pbh_last_error()

@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard channels, run the per-shard transform
+(the oracle stands in for the HIP plan through the _transform test hook) and all-gather.  The
+result must equal the oracle on the full block, which pins the shard bookkeeping: channel
+partition, per-shard channel frequencies, full-band crop, start_time and the gather order."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import pulsarbat_amd as pb
+from pulsarbat_amd import shard, units as u
+from oracle import dedisp_oracle as orc
+
+SHAPE, DM, SR, FC = (4096, 6, 2), 8.0, 1e6, 1e9
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_transform(x, start, stop, freqs_hz, ref_hz):
+    chirp = np.stack([orc.transfer_function(DM, x.shape[0], 1 / SR, f, ref_hz) for f in freqs_hz], axis=1)
+    import scipy.fft
+    y = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * chirp[:, :, None], axis=0)
+    return np.ascontiguousarray(y[start:stop])
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = orc.synthetic_block(SHAPE, 5)
+    z = pb.DualPolarizationSignal(x, sample_rate=SR * u.Hz, center_freq=FC * u.Hz, pol_type="linear",
+                                  start_time=pb.Time(56000.0, format="mjd"))
+    zl = shard.shard_signal(z, world, rank)
+    full = shard.coherent_dedispersion_sharded(
+        zl, pb.DM(DM), band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq,
+        gather=True, _transform=_oracle_transform)
+    local = shard.coherent_dedispersion_sharded(
+        zl, pb.DM(DM), band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq,
+        gather=False, _transform=_oracle_transform)
+    q.put((rank, np.asarray(full), full.channel_freqs.to_value(u.Hz),
+           (full.start_time - z.start_time).to_value(u.s), np.asarray(local).shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_channel_slice():
+    for nchan, world in ((8, 2), (64, 8), (6, 4), (5, 2), (3, 3)):
+        got = []
+        for r in range(world):
+            sl = shard.channel_slice(nchan, world, r)
+            got.extend(range(sl.start, sl.stop))
+        assert got == list(range(nchan))
+    with pytest.raises(ValueError):
+        shard.channel_slice(8, 2, 2)
+
+
+def test_sharded_equals_full_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = orc.synthetic_block(SHAPE, 5)
+    want, start, stop = orc.coherent_dedispersion(x, DM, SR, FC)
+    fwant = orc.channel_freqs(FC, SR, SHAPE[1])
+    for rank, full, freqs, dt, lshape in results:
+        assert full.shape == want.shape
+        assert np.allclose(full, want, rtol=0, atol=1e-6)
+        assert np.allclose(freqs, fwant)
+        assert abs(dt - start / SR) < 1e-12
+        assert lshape == (stop - start, SHAPE[1] // world, SHAPE[2])
