@@ -81,7 +81,9 @@ static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
 static int resolved_variant(const pbh_plan* p) {
     if (p->N1 == 1) return PBH_VARIANT_DIRECT3;  // single tile: no passes to choose
     if (p->variant != PBH_VARIANT_AUTO) return p->variant;
-    return PBH_VARIANT_DIRECT3;
+    // direct3 touches full 128-B lines only when a 16-column tile spans whole time samples of few
+    // series; with many interleaved series its planar side degenerates to 8-byte pieces
+    return p->S <= 2 ? PBH_VARIANT_DIRECT3 : PBH_VARIANT_PLANAR5;
 }
 
 // ---- kernel dispatch by FFT length ---------------------------------------------------------------------------

@@ -1,0 +1,30 @@
+"""profiles/traffic.json from a tools/prof.sh run: HBM bytes per launch per kernel, from the PMC
+passes, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts half of a wide coalesced
+read on gfx950 -> x2; WRITE_SIZE exact; both in KiB)."""
+import csv, glob, json, os, sys, collections
+root, out = sys.argv[1], sys.argv[2]
+NAMES = {"k_row": "k_row_fused", "k_deinterleave": "k_deinterleave", "k_reinterleave": "k_reinterleave",
+         "k_small": "k_small"}
+def step(kname):
+    k = kname.replace("void pbh::", "").replace("pbh::", "")
+    if k.startswith("k_col<"):
+        return "k_col_inv" if k.split(",")[1].strip().startswith("1") else "k_col_fwd"
+    for a, b in NAMES.items():
+        if k.startswith(a):
+            return b
+    return None
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            s = step(r["Kernel_Name"])
+            if s:
+                acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for s, c in acc.items():
+    fetch = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))
+    write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
+    res[s] = (2.0 * fetch + write) * 1024.0
+res["_source"] = os.path.basename(root) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch"
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
