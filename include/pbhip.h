@@ -57,8 +57,10 @@ typedef enum {
 typedef enum {
     PBH_VARIANT_AUTO = 0,
     PBH_VARIANT_PLANAR5 = 1, /* de-interleave, column FFT, fused row pass, column IFFT, re-interleave+crop */
-    PBH_VARIANT_DIRECT3 = 2  /* column FFT straight from the interleaved block, fused row pass,
+    PBH_VARIANT_DIRECT3 = 2, /* column FFT straight from the interleaved block, fused row pass,
                                 column IFFT straight into the cropped interleaved output */
+    PBH_VARIANT_BLOCK3 = 3   /* as DIRECT3 with column tiles of 4 series x (F/4) time columns: 32-byte
+                                pieces on both sides, line-sharing tiles co-located on one XCD        */
 } pbh_variant;
 
 typedef struct {

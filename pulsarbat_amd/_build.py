@@ -34,7 +34,9 @@ def build(force=False, verbose=False):
     """Compile the HIP library if missing or older than its sources; returns its path."""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: v_pk_*_f32 has no rate advantage on gfx950 and its even-aligned register
+    # pairs inflate VGPR pressure in the fully unrolled butterflies
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
            "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     with open(os.path.join(CSRC, "build.log"), "w") as fh:

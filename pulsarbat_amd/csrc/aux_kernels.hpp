@@ -106,6 +106,82 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
     }
 }
 
+// Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
+// moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the
+// streaming-copy calibration (tools/micro/membench.hip) found fastest on MI355X.
+template <int S>
+__global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
+                                                         int64_t N, int64_t plane) {
+    constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;  // 8 float4 per thread
+    __shared__ cf lds[S * LD];
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const float4* src = reinterpret_cast<const float4*>(in + n0 * S);
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = src[threadIdx.x + 256 * j];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = 2 * (threadIdx.x + 256 * j);
+        const int n = e / S, s = e % S;
+        if (S == 1) {  // two consecutive times of the single series
+            lds[e] = make_float2(v[j].x, v[j].y);
+            lds[e + 1] = make_float2(v[j].z, v[j].w);
+        } else {
+            lds[s * LD + n] = make_float2(v[j].x, v[j].y);
+            lds[(s + 1) * LD + n] = make_float2(v[j].z, v[j].w);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int pidx = threadIdx.x + 256 * j;
+        const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
+        const cf a = lds[s * LD + n], b = lds[s * LD + n + 1];
+        *reinterpret_cast<float4*>(out + (int64_t)s * plane + n0 + n) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// planar [s][t] -> (stop-start, S); the tail tile is handled by the generic kernel
+template <int S>
+__global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
+                                                         int64_t start, int64_t plane) {
+    constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;
+    __shared__ cf lds[S * LD];
+    const int64_t t0 = start + (int64_t)blockIdx.x * TN;
+    cf a[NV], b[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int pidx = threadIdx.x + 256 * j;
+        const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
+        const cf* p = in + (int64_t)s * plane + t0 + n;
+        a[j] = p[0];
+        b[j] = p[1];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int pidx = threadIdx.x + 256 * j;
+        const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
+        lds[s * LD + n] = a[j];
+        lds[s * LD + n + 1] = b[j];
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(out + (t0 - start) * S);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = 2 * (threadIdx.x + 256 * j);
+        const int n = e / S, s = e % S;
+        cf x, y;
+        if (S == 1) {
+            x = lds[e];
+            y = lds[e + 1];
+        } else {
+            x = lds[s * LD + n];
+            y = lds[(s + 1) * LD + n];
+        }
+        dst[threadIdx.x + 256 * j] = make_float4(x.x, x.y, y.x, y.y);
+    }
+}
+
 // ---- detection (pulsarbat/core.py:766-774, 930-966), optional time scrunch -----------------------------
 // in: (n, nchan, npol) c64.  One thread per (output row, chan); sums nscrunch input rows in float32.
 __global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float* __restrict__ out,

@@ -87,6 +87,14 @@ static int resolved_variant(const pbh_plan* p) {
 }
 
 // ---- kernel dispatch by FFT length ---------------------------------------------------------------------------
+static int block_lane_order() {
+    static int r = [] {
+        const char* e = getenv("PBH_BLOCK_LANE_ORDER");
+        return e ? atoi(e) : 0;
+    }();
+    return r;
+}
+
 static int col_points_per_thread() {
     static int r = [] {
         const char* e = getenv("PBH_COL_R");
@@ -115,19 +123,35 @@ static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads
 
 #define FOR_ALL_M(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
 
+static int row_grid() {
+    static int g = [] {
+        const char* e = getenv("PBH_ROW_GRID");
+        int v = e ? atoi(e) : 0;
+        if (v > 0) return v;
+        int dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus;  // one persistent workgroup per CU (LDS admits one)
+    }();
+    return g;
+}
+
 template <int OP>
-static int launch_col(int M, const ColParams& prm, hipStream_t st) {
+static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
     const int F = kTilePoints / M;
-    const int64_t tiles = (prm.ncols + F - 1) / F;
+    ColParams prm = prm0;
+    const int64_t ntile = (prm.ncols + F - 1) / F;
+    if (ntile > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "too many column tiles");
+    prm.ntile = (int)ntile;
     if (col_points_per_thread() == 16) {
         switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 16>, prm, tiles, kTilePoints / 16, st);
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 16>, prm, ntile, kTilePoints / 16, st);
             FOR_ALL_M(X)
 #undef X
         }
     }
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32>, prm, tiles, kTilePoints / 32, st);
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32>, prm, ntile, kTilePoints / 32, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -136,9 +160,14 @@ static int launch_col(int M, const ColParams& prm, hipStream_t st) {
 
 static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     const int FR = kTilePoints / M;
-    const int64_t tiles = (prm.nrows + FR - 1) / FR;
+    int64_t tiles = (prm.nrows + FR - 1) / FR;
+    if (tiles > row_grid()) tiles = row_grid();
+    static int mode = [] { const char* e = getenv("PBH_ROW_MODE"); return e ? atoi(e) : 0; }();
+    if (M == 16384 && mode == 1) return launch_tile_kernel(k_row<16384, 32, false>, prm, tiles, kTilePoints / 32, st);
+    if (M == 16384 && mode == 2) return launch_tile_kernel(k_row<16384, 16, false>, prm, tiles, kTilePoints / 16, st);
+    if (M == 16384 && mode == 3) return launch_tile_kernel(k_row<16384, 16, true>, prm, tiles, kTilePoints / 16, st);
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_row<m, 32>, prm, tiles, kTilePoints / 32, st);
+#define X(m) case m: return launch_tile_kernel(k_row<m, 32, true>, prm, tiles, kTilePoints / 32, st);
         X(1024) X(2048) X(4096) X(8192) X(16384)
 #undef X
     }
@@ -161,6 +190,49 @@ static int tr_rows(int S) {
     return tn < 1 ? 1 : tn;
 }
 
+static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
+    const int TN = tr_rows(S);
+    if ((S & (S - 1)) == 0 && S <= 32 && N % TN == 0) {
+        const unsigned grid = (unsigned)(N / TN);
+        switch (S) {
+#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, N); break;
+            X(1) X(2) X(4) X(8) X(16) X(32)
+#undef X
+        }
+    } else {
+        hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
+                           (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N);
+    }
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane,
+                               hipStream_t st) {
+    if (stop <= start) return PBH_OK;
+    const int TN = tr_rows(S);
+    int64_t done = 0;
+    if ((S & (S - 1)) == 0 && S <= 32) {
+        const int64_t full = (stop - start) / TN;
+        if (full > 0) {
+            switch (S) {
+#define X(s) case s: hipLaunchKernelGGL(k_reinterleave_p2<s>, dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane); break;
+                X(1) X(2) X(4) X(8) X(16) X(32)
+#undef X
+            }
+            HIPCHECK(hipGetLastError());
+        }
+        done = full * TN;
+    }
+    if (start + done < stop) {  // tail (or everything, for other S) through the generic kernel
+        const int64_t s2 = start + done;
+        hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - s2 + TN - 1) / TN)), dim3(256),
+                           (size_t)TN * (S + 1) * sizeof(cf), st, work, out + done * S, s2, stop, S, TN, plane);
+        HIPCHECK(hipGetLastError());
+    }
+    return PBH_OK;
+}
+
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
     std::vector<Step> steps;
@@ -174,40 +246,33 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
     const int variant = resolved_variant(p);
     BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, p->N - 1};
     const int64_t ncols = (int64_t)S * p->N2;
-    ColSide planar{LAYOUT_PLANAR, p->N};
-    ColSide inter{LAYOUT_INTERLEAVED, 0};
+    ColSide planar{LAYOUT_PLANAR, p->N, p->N2};
+    ColSide inter{LAYOUT_INTERLEAVED, 0, (int64_t)p->N2 * S};
     const int N1 = p->N1, N2 = p->N2;
     cf* work = p->work;
 
     if (variant == PBH_VARIANT_PLANAR5) {
-        const int TN = tr_rows(S);
-        const size_t trlds = (size_t)TN * (S + 1) * sizeof(cf);
         const int64_t N = p->N, start = p->start, stop = p->stop;
         steps.push_back({"k_deinterleave", [=](hipStream_t st) {
-            hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256), trlds, st,
-                               in, work, N, S, TN, N);
-            HIPCHECK(hipGetLastError());
-            return (int)PBH_OK;
+            return launch_deinterleave(in, work, N, S, st);
         }});
-        ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, S, N2, ncols, tw, p->tw16k, 0, N, 0};
+        ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
-        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, S, N2, ncols, tw, p->tw16k, 0, N, 0};
+        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
         steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-            if (stop <= start) return (int)PBH_OK;
-            hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - start + TN - 1) / TN)), dim3(256),
-                               trlds, st, (const cf*)work, out, start, stop, S, TN, N);
-            HIPCHECK(hipGetLastError());
-            return (int)PBH_OK;
+            return launch_reinterleave(work, out, start, stop, S, N, st);
         }});
     } else {
-        ColParams c1{in, work, inter, planar, LAYOUT_INTERLEAVED, S, N2, ncols, tw, p->tw16k, 0, p->N, 0};
+        const int el = (variant == PBH_VARIANT_BLOCK3) ? LAYOUT_BLOCK : LAYOUT_INTERLEAVED;
+        const int sb = 4, lo = block_lane_order();
+        ColParams c1{in, work, inter, planar, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k, 0, p->N, 0};
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
-        ColParams c3{work, out, planar, inter, LAYOUT_INTERLEAVED, S, N2, ncols, tw, p->tw16k,
+        ColParams c3{work, out, planar, inter, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k,
                      p->start, p->stop, p->start * S};
         steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
     }
@@ -340,7 +405,12 @@ int pbh_plan_set_stream(pbh_plan* p, void* hip_stream) {
 
 int pbh_plan_set_variant(pbh_plan* p, int variant) {
     if (!p) return fail(PBH_ERR_INVALID, "plan is NULL");
-    if (variant < PBH_VARIANT_AUTO || variant > PBH_VARIANT_DIRECT3) return fail(PBH_ERR_INVALID, "bad variant");
+    if (variant < PBH_VARIANT_AUTO || variant > PBH_VARIANT_BLOCK3) return fail(PBH_ERR_INVALID, "bad variant");
+    if (variant == PBH_VARIANT_BLOCK3 && p->N1 > 1) {
+        const int F = kTilePoints / p->N1;
+        if (F < 16 || p->S % 4 != 0 || p->N2 % (F / 4 > 16 ? F / 4 : 16) != 0)
+            return fail(PBH_ERR_UNSUPPORTED, "block3 needs nchan*npol % 4 == 0 and nsample <= 2^24");
+    }
     p->variant = variant;
     return PBH_OK;
 }
