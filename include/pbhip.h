@@ -118,6 +118,15 @@ int pbh_dedisperse(pbh_plan* plan, const void* in_c64, void* out_c64, int in_loc
 int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int nscrunch, int mode,
                           int in_loc, int out_loc);
 
+/* Streaming overlap-save over a long HOST-resident block (BASELINE configs[3]): chunks of the plan's
+ * nsample rows every hop = crop_stop - crop_start rows; chunk k is one reference call on
+ * in[k*hop : k*hop + nsample] (dedispersion.py:81-133) and fills out rows [k*hop, (k+1)*hop) --
+ * concatenate() of the chunk results (transforms.py:59-148).  H2D / kernels / D2H are double-buffered
+ * on three HIP streams.  in : (total_nsample, nchan, npol) c64 host;  out: (nchunk*hop, nchan, npol) c64
+ * host, nchunk = (total_nsample - nsample) / hop + 1 (returned).  ms_total (optional): HIP-event time. */
+int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsample, void* host_out,
+                          int64_t* nchunk, float* ms_total);
+
 /* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
 int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, int64_t nsample,
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);

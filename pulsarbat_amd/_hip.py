@@ -56,6 +56,8 @@ SIGNATURES = {
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_float)]),
     "pbh_detect": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, C.c_int]),
     "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
@@ -242,6 +244,25 @@ class Plan:
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))
         return out
+
+    def dedisperse_stream(self, x_host, out=None):
+        """Overlap-save over a long host block: (total, nchan, npol) c64 -> (nchunk*hop, ...), plus ms."""
+        if not isinstance(x_host, np.ndarray) or x_host.dtype != np.complex64 or not x_host.flags.c_contiguous:
+            raise TypeError("dedisperse_stream needs a C-contiguous complex64 numpy array")
+        if int(np.prod(x_host.shape[1:])) != self.nchan * self.npol:
+            raise ValueError("sample shape does not match the plan")
+        hop = self.nout
+        if hop <= 0 or x_host.shape[0] < self.nsample:
+            raise ValueError("empty valid region or input shorter than one chunk")
+        nchunk = (x_host.shape[0] - self.nsample) // hop + 1
+        if out is None:
+            out = np.empty((nchunk * hop,) + tuple(x_host.shape[1:]), dtype=np.complex64)
+        self._sync_stream()
+        n, ms = C.c_int64(), C.c_float()
+        _check(lib().pbh_dedisperse_stream(self._h, C.c_void_p(x_host.ctypes.data), int(x_host.shape[0]),
+                                           C.c_void_p(out.ctypes.data), C.byref(n), C.byref(ms)))
+        assert n.value == nchunk
+        return out, float(ms.value)
 
     def profile(self, x_dev, out_dev, iters=10):
         """Mean per-kernel milliseconds (hipEvents on the plan's stream): list of (name, ms)."""

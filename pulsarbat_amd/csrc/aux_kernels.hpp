@@ -225,6 +225,61 @@ __global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float
     }
 }
 
+// ---- fused detection + time scrunch from the planar work buffer (tail of the PLANAR5 sequence) ------------
+// Replaces k_reinterleave when the caller wants detected, time-scrunched output (BASELINE configs[4]):
+// the dedispersed voltages are never written in the reference layout.  One wavefront owns one output
+// bin of one channel: lanes stride over the bin's nscrunch consecutive samples (coalesced 512-B reads
+// per polarisation), accumulate in float32 and finish with a 64-lane butterfly reduction.
+//   mode 0: |z|^2 per pol -> out[o][chan][pol];  1: Stokes I -> out[o][chan];  2/3: IQUV -> out[o][chan][4]
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ work, float* __restrict__ out,
+                                                       int64_t plane, int64_t start, int64_t nout, int nchan,
+                                                       int npol, int mode, int nscrunch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t o = (int64_t)blockIdx.x * 4 + wave;
+    const int chan = blockIdx.y;
+    if (o >= nout) return;
+    const int64_t t0 = start + o * nscrunch;
+    if (mode == 0) {
+        for (int pp = 0; pp < npol; ++pp) {
+            const cf* a = work + (int64_t)(chan * npol + pp) * plane + t0;
+            float acc = 0.f;
+            for (int i = lane; i < nscrunch; i += 64) acc += a[i].x * a[i].x + a[i].y * a[i].y;
+            acc = wave_sum(acc);
+            if (lane == 0) out[(o * nchan + chan) * npol + pp] = acc;
+        }
+        return;
+    }
+    const cf* pa = work + (int64_t)(chan * 2) * plane + t0;
+    const cf* pb = pa + plane;
+    float si = 0.f, sq = 0.f, su = 0.f, sv = 0.f;
+    for (int i = lane; i < nscrunch; i += 64) {
+        const cf a = pa[i], b = pb[i];
+        const float aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
+        si += aa + bb;
+        if (mode >= 2) {
+            const float re = a.x * b.x + a.y * b.y, im = a.x * b.y - a.y * b.x;  // conj(a) * b
+            if (mode == 2) { sq += aa - bb; su += 2.f * re; sv += 2.f * im; }
+            else { sq += 2.f * re; su += 2.f * im; sv += aa - bb; }
+        }
+    }
+    si = wave_sum(si);
+    if (mode == 1) {
+        if (lane == 0) out[o * nchan + chan] = si;
+        return;
+    }
+    sq = wave_sum(sq); su = wave_sum(su); sv = wave_sum(sv);
+    if (lane == 0) {
+        float* o4 = out + (o * nchan + chan) * 4;
+        o4[0] = si; o4[1] = sq; o4[2] = su; o4[3] = sv;
+    }
+}
+
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
 //   w     : seeds from load_tw_seeds<M, 1, R> (forward sign; conjugated here for DIR = +1)
 // fofs must be a multiple of 32 when PS == 1 (row tiles: fofs = f * M).
 // Must be called by all threads of the workgroup (contains barriers).
-template <int M, int NS, int R, int DIR, int PS, bool PAD>
+template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false>
 __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w) {
     if constexpr (NS < M) {
         constexpr int RAD = stage_radix(M, NS, R);
@@ -249,6 +249,11 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
             if constexpr (LAST) {
 #pragma unroll
                 for (int u = 0; u < RAD; ++u) v[q + u * NB] = t[u];
+            } else if constexpr (XS) {
+                // split exchange (half the LDS): park the butterfly outputs back in v; the real and
+                // imaginary parts go through a float buffer one after the other below
+#pragma unroll
+                for (int u = 0; u < RAD; ++u) v[q + u * NB] = t[u];
             } else {
                 const int base = (jb - k) * RAD + k;
                 // linear form is exact when the step is a multiple of 32 slots, or when it is the
@@ -264,7 +269,30 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 }
             }
         }
-        if constexpr (!LAST) {
+        if constexpr (!LAST && XS) {
+            static_assert(!PAD, "split exchange is implemented for unpadded (column) tiles");
+            float* fl = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int jb = tau + q * MR;
+                    const int k = jb & (NS - 1);
+                    float* wp = fl + ((jb - k) * RAD + k) * PS + fofs;
+#pragma unroll
+                    for (int u = 0; u < RAD; ++u) wp[u * NS * PS] = part ? v[q + u * NB].y : v[q + u * NB].x;
+                }
+                __syncthreads();
+                const float* rp = fl + tau * PS + fofs;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    if (part) v[i].y = rp[i * MR * PS];
+                    else v[i].x = rp[i * MR * PS];
+                }
+                __syncthreads();
+            }
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
+        } else if constexpr (!LAST) {
             __syncthreads();
             constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
             if constexpr (RLIN) {
@@ -276,7 +304,7 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 for (int i = 0; i < R; ++i) v[i] = lds[lds_phys<PAD>((tau + i * MR) * PS + fofs)];
             }
             __syncthreads();
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
         }
     }
 }

@@ -96,9 +96,11 @@ __device__ __forceinline__ bool col_decode(const ColParams& p, int64_t tile, int
     return true;
 }
 
-// Generic column pass (any pair of layouts): one tile per workgroup.
-template <int M, int OP, int R>
-__global__ __launch_bounds__(kTilePoints / R) void k_col(ColParams p) {
+// Generic column pass (any pair of layouts): one tile per workgroup.  XS = split (re, then im)
+// LDS exchange: 64 KiB instead of 128 KiB and a 128-VGPR cap, so TWO workgroups share a CU and
+// one's loads/stores overlap the other's butterflies.
+template <int M, int OP, int R, bool XS>
+__global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p) {
     constexpr int F = kTilePoints / M;  // columns per tile
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;           // row stride between a thread's points
@@ -134,14 +136,14 @@ __global__ __launch_bounds__(kTilePoints / R) void k_col(ColParams p) {
             v[i] = cmul(v[i], make_float2((float)z.x, (float)-z.y));
             z = zmul(z, zs);
         }
-        fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, +1, F, PAD, XS>(v, lds, tau, f, w);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int64_t t = (int64_t)(tau + i * MR) * p.N2 + n2;
             if (valid && t >= p.crop_start && t < p.crop_stop) dst[i * ostep] = v[i];
         }
     } else {
-        fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
+        fft_tile<M, 1, R, -1, F, PAD, XS>(v, lds, tau, f, w);
         double2 z = zb;
 #pragma unroll
         for (int i = 0; i < R; ++i) {

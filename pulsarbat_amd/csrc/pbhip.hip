@@ -95,20 +95,11 @@ static int block_lane_order() {
     return r;
 }
 
-static int col_points_per_thread() {
-    static int r = [] {
-        const char* e = getenv("PBH_COL_R");
-        int v = e ? atoi(e) : 32;
-        return (v == 16) ? 16 : 32;
-    }();
-    return r;
-}
-
 template <typename K, typename P>
-static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads, hipStream_t st) {
+static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads, hipStream_t st,
+                              size_t lds = lds_tile_bytes<true>() /* 132 KiB: tile + 1 pad slot per 32 */) {
     static thread_local const void* configured[128];
     static thread_local int nconf = 0;
-    const size_t lds = lds_tile_bytes<true>();  // 132 KiB: the tile plus one pad slot per 32
     bool seen = false;
     for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
     if (!seen) {
@@ -143,15 +134,10 @@ static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
     const int64_t ntile = (prm.ncols + F - 1) / F;
     if (ntile > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "too many column tiles");
     prm.ntile = (int)ntile;
-    if (col_points_per_thread() == 16) {
-        switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 16>, prm, ntile, kTilePoints / 16, st);
-            FOR_ALL_M(X)
-#undef X
-        }
-    }
+    // (a split re/im exchange variant, k_col<..., true>, gives two workgroups per CU; it measured
+    //  slower -- 1.14 vs 0.98 ms -- because the 128-VGPR cap spills: not instantiated)
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32>, prm, ntile, kTilePoints / 32, st);
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32, false>, prm, ntile, kTilePoints / 32, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -234,7 +220,15 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
 }
 
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
-static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
+struct DetectTail {
+    float* out = nullptr;  // non-null: replace the final layout pass by detect + scrunch into `out`
+    int mode = 0, nscrunch = 1;
+};
+
+// true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
+static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
+
+static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail()) {
     std::vector<Step> steps;
     const int S = p->S;
     if (p->N1 == 1) {
@@ -260,11 +254,24 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
-        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
+        // rows outside [start, stop) are never read by k_reinterleave: skip their stores
+        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
         steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
-        steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-            return launch_reinterleave(work, out, start, stop, S, N, st);
-        }});
+        if (tail.out) {
+            const int nchan = p->nchan, npol = p->npol;
+            const int64_t nout = (stop - start) / tail.nscrunch;
+            steps.push_back({"k_detect_planar", [=](hipStream_t st) {
+                if (nout <= 0) return (int)PBH_OK;
+                hipLaunchKernelGGL(k_detect_planar, dim3((unsigned)((nout + 3) / 4), (unsigned)nchan), dim3(256), 0, st,
+                                   (const cf*)work, tail.out, N, start, nout, nchan, npol, tail.mode, tail.nscrunch);
+                HIPCHECK(hipGetLastError());
+                return (int)PBH_OK;
+            }});
+        } else {
+            steps.push_back({"k_reinterleave", [=](hipStream_t st) {
+                return launch_reinterleave(work, out, start, stop, S, N, st);
+            }});
+        }
     } else {
         const int el = (variant == PBH_VARIANT_BLOCK3) ? LAYOUT_BLOCK : LAYOUT_INTERLEAVED;
         const int sb = 4, lo = block_lane_order();
@@ -277,6 +284,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out) {
         steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
     }
     return steps;
+}
+
+static bool can_fuse_detect(const pbh_plan* p, int nscrunch) {
+    return p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && nscrunch % 64 == 0 && p->nchan <= 65535;
 }
 
 static int run_steps(std::vector<Step>& steps, hipStream_t st) {
@@ -638,8 +649,15 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     const cf* din;
     void* dout;
     PBHCHECK(resolve_io(p, in_c64, out_f32, out_bytes, in_loc, out_loc, &din, &dout));
-    if (nout > 0) {
-        // round-1 form: dedisperse into a device buffer, then detect+scrunch (fused tail: see DESIGN.md)
+    if (nout > 0 && can_fuse_detect(p, nscrunch)) {
+        DetectTail tail;
+        tail.out = (float*)dout;
+        tail.mode = mode;
+        tail.nscrunch = nscrunch;
+        auto steps = build_steps(p, din, nullptr, tail);
+        PBHCHECK(run_steps(steps, p->stream));
+    } else if (nout > 0) {
+        // unfused form: dedisperse into a device buffer, then detect + scrunch
         void* mid = nullptr;
         PBHCHECK(dev_alloc(nullptr, &mid, mid_bytes));
         auto steps = build_steps(p, din, (cf*)mid);
@@ -707,6 +725,109 @@ int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64,
     if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_fft_c2c: ") + hipGetErrorString(e));
     return PBH_OK;
+}
+
+// ---- streaming overlap-save (BASELINE configs[3]) ---------------------------------------------------------------------
+// A long host-resident block is dedispersed in chunks of plan->N samples that overlap by N - hop,
+// hop = stop - start: chunk k covers input rows [k*hop, k*hop + N) and yields output rows
+// [k*hop, (k+1)*hop) -- exactly `concatenate([coherent_dedispersion(z[k*hop : k*hop+N]) for k])` of the
+// reference (each chunk is one reference call; its crop is the valid region of an overlap-save step:
+// dedispersion.py:127-133, transforms.py:59-148).  Two device in/out buffer pairs; H2D, kernels and
+// D2H run on three streams chained by events so chunk k+1 uploads while chunk k computes and chunk
+// k-1 downloads.  Host memory is page-locked for the duration of the call (hipHostRegister).
+int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsample, void* host_out,
+                          int64_t* nchunk_out, float* ms_total) {
+    if (!p || !host_in || !host_out) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    const int64_t hop = p->stop - p->start;
+    if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
+    if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
+    const int64_t nchunk = (total_nsample - p->N) / hop + 1;
+    HIPCHECK(hipSetDevice(p->device));
+    const size_t row = sizeof(cf) * (size_t)p->S;
+    const size_t in_bytes = row * (size_t)p->N, out_bytes = row * (size_t)hop;
+    const size_t host_in_bytes = row * (size_t)total_nsample, host_out_bytes = out_bytes * (size_t)nchunk;
+
+    void* din[2] = {nullptr, nullptr};
+    void* dout[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool reg_in = false, reg_out = false;
+    int rc = PBH_OK;
+    auto hipok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
+        if ((rc = dev_alloc(nullptr, &din[b], in_bytes)) != PBH_OK) break;
+        rc = dev_alloc(nullptr, &dout[b], out_bytes);
+    }
+    if (rc == PBH_OK) {
+        // pinning is best effort: pageable memory still works (copies just stop overlapping)
+        reg_in = hipHostRegister(const_cast<void*>(host_in), host_in_bytes, hipHostRegisterDefault) == hipSuccess;
+        reg_out = hipHostRegister(host_out, host_out_bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+        hipok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
+        hipok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
+        hipok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
+        for (int b = 0; b < 2; ++b) {
+            hipok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
+            hipok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
+            hipok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
+        }
+        hipok(hipEventCreate(&t0), "hipEventCreate");
+        hipok(hipEventCreate(&t1), "hipEventCreate");
+    }
+    if (rc == PBH_OK) {
+        // the plan's own stream may hold pending work (chirp generation): order after it
+        hipok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
+        hipok(hipEventRecord(t0, s_in), "hipEventRecord");
+        hipok(hipStreamWaitEvent(s_cmp, t0, 0), "hipStreamWaitEvent");
+        for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
+            const int b = (int)(k & 1);
+            const char* src = (const char*)host_in + (size_t)(k * hop) * row;
+            char* dst = (char*)host_out + (size_t)k * out_bytes;
+            if (k >= 2) hipok(hipStreamWaitEvent(s_in, ev_cmp[b], 0), "hipStreamWaitEvent");  // in[b] consumed
+            hipok(hipMemcpyAsync(din[b], src, in_bytes, hipMemcpyHostToDevice, s_in), "hipMemcpyAsync H2D");
+            hipok(hipEventRecord(ev_in[b], s_in), "hipEventRecord");
+            hipok(hipStreamWaitEvent(s_cmp, ev_in[b], 0), "hipStreamWaitEvent");
+            if (k >= 2) hipok(hipStreamWaitEvent(s_cmp, ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
+            if (rc == PBH_OK) {
+                auto steps = build_steps(p, (const cf*)din[b], (cf*)dout[b]);
+                rc = run_steps(steps, s_cmp);
+            }
+            hipok(hipEventRecord(ev_cmp[b], s_cmp), "hipEventRecord");
+            hipok(hipStreamWaitEvent(s_out, ev_cmp[b], 0), "hipStreamWaitEvent");
+            hipok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, s_out), "hipMemcpyAsync D2H");
+            hipok(hipEventRecord(ev_out[b], s_out), "hipEventRecord");
+        }
+        hipok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
+        hipok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
+        hipok(hipEventRecord(t1, s_out), "hipEventRecord");
+        hipok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
+        if (rc == PBH_OK && ms_total) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, t0, t1);
+            *ms_total = ms;
+        }
+    }
+    if (reg_in) hipHostUnregister(const_cast<void*>(host_in));
+    if (reg_out) hipHostUnregister(host_out);
+    for (int b = 0; b < 2; ++b) {
+        if (din[b]) hipFree(din[b]);
+        if (dout[b]) hipFree(dout[b]);
+        if (ev_in[b]) hipEventDestroy(ev_in[b]);
+        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
+        if (ev_out[b]) hipEventDestroy(ev_out[b]);
+    }
+    if (t0) hipEventDestroy(t0);
+    if (t1) hipEventDestroy(t1);
+    if (s_in) hipStreamDestroy(s_in);
+    if (s_cmp) hipStreamDestroy(s_cmp);
+    if (s_out) hipStreamDestroy(s_out);
+    if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
+    return rc;
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ __all__ = [
     "DM",
     "coherent_dedispersion",
     "dedisperse_detect",
+    "coherent_dedispersion_stream",
 ]
 
 _DM_UNIT = u.pc / u.cm ** 3
@@ -221,3 +222,27 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     """
     plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant)
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
+
+
+def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto"):
+    """Overlap-save dedispersion of a long host-resident signal in chunks of ``chunk`` samples.
+
+    Equals ``pb.concatenate([coherent_dedispersion(z[k*hop : k*hop + chunk], DM, ref_freq=ref)
+    for k in range(nchunk)])`` with ``hop`` the valid length of one chunk (the reference's own
+    recipe for long series: SURVEY.md 5, transforms.py:59-148), but uploads chunk k+1 and downloads
+    chunk k-1 while chunk k is on the GPU (double-buffered hipMemcpyAsync).  Returns the signal
+    (start_time advanced by the crop start) and the HIP-event milliseconds of the whole stream.
+    """
+    if not isinstance(z, BasebandSignal):
+        raise TypeError("Signal must be a BasebandSignal object.")
+    if isinstance(z.data, DeviceArray):
+        raise TypeError("coherent_dedispersion_stream takes a host-resident signal")
+    if z.dtype != np.complex64:
+        raise NotImplementedError("the HIP path computes in complex64")
+    if ref_freq is None:
+        ref_freq = z.center_freq
+    head = z[:chunk]
+    start, stop = _crop_bounds(head, DM, ref_freq)
+    plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
+    y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
+    return type(z).like(z, y, **_advance(z, start)), ms

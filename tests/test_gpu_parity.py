@@ -287,3 +287,42 @@ def test_full_size_properties():
     got = y1.data.tensor[:, c, p].cpu().numpy()
     e = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     assert e < RTOL_L2, f"series ({c},{p}) relative L2 {e:.2e}"
+
+
+@pytest.mark.parametrize("mode,k", [("I", 1024), ("linear", 256), ("circular", 64), ("intensity", 128),
+                                    ("I", 48), ("linear", 1)])
+def test_detect_scrunch_modes(mode, k):
+    """Fused (k % 64 == 0, planar5) and unfused detect tails against the oracle."""
+    shape, dm, sr, fc = (1 << 17, 4, 2), 20.0, 1e6, 1e9
+    x = orc.synthetic_block(shape, 12)
+    z = make_signal(x, sr, fc)
+    got, start = pb.dedisperse_detect(z, pb.DM(dm), mode=mode, nscrunch=k)
+    yr, s0, _ = orc.coherent_dedispersion(x, dm, sr, fc)
+    if mode == "intensity":
+        want = orc.scrunch(orc.to_intensity(yr), k)
+    elif mode == "I":
+        want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], k)
+    else:
+        want = orc.scrunch(orc.to_stokes(yr, mode), k)
+    assert start == s0 and got.shape == want.shape and got.dtype == np.float32
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 3e-5 * scale * max(1.0, np.sqrt(k) / 4)
+
+
+@pytest.mark.parametrize("shape,chunk,dm", [((1 << 18, 4, 2), 1 << 15, 20.0), ((300000, 2, 2), 1 << 16, 50.0),
+                                            ((1 << 16, 3), 1 << 14, 5.0)])
+def test_stream_overlap_save(shape, chunk, dm):
+    """BASELINE configs[3] (overlap-save streaming) at small size: equals the concatenation of
+    per-chunk reference calls, and is time-contiguous with the single-call result."""
+    sr, fc = 1e6, 1e9
+    x = orc.synthetic_block(shape, 21)
+    z = make_signal(x, sr, fc, start_time=pb.Time(56000.0, format="mjd"))
+    y, ms = pb.coherent_dedispersion_stream(z, pb.DM(dm), chunk=chunk)
+    first, start, stop = orc.coherent_dedispersion(x[:chunk], dm, sr, fc)
+    hop = stop - start
+    nchunk = (shape[0] - chunk) // hop + 1
+    assert len(y) == nchunk * hop and ms > 0
+    want = np.concatenate([orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, sr, fc)[0]
+                           for k in range(nchunk)], axis=0)
+    assert series_errors(y, want)[0] < RTOL_L2
+    assert abs((y.start_time - z.start_time).to_value(u.s) - start / sr) < 1e-12
