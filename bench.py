@@ -48,12 +48,13 @@ def log(*a):
 def cpu_baseline():
     """Oracle (numpy + scipy.fft restatement of the reference) on a bounded sample.
 
-    Sample: (2^22, 8, 2) complex64 = 1/4 of the workload's time axis with the same channel
-    layout, chirp precomputed, scipy.fft workers=None (one thread: what the reference runs,
-    pulsarbat/fft.py:36-38).  A second figure uses all host cores (not reference behaviour).
+    Sample: ONE full workload block, (2^24, 8, 2) complex64, chirp precomputed (timed separately),
+    scipy.fft workers=None (one thread: what the reference runs, pulsarbat/fft.py:36-38); about
+    10-20 s of CPU work on the GPU node's host.  A second figure uses all host cores (not reference
+    behaviour).
     """
     from oracle import dedisp_oracle as orc
-    n = 1 << 22
+    n = 1 << 24
     shape = (n, NCHAN_PER_GPU, NPOL)
     x = orc.synthetic_block(shape, 20260002)
     sr = BAND_HZ / NCHAN_PER_GPU
@@ -70,7 +71,7 @@ def cpu_baseline():
     nsamp = float(np.prod(shape))
     return {
         "value": nsamp / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-        "sample": "oracle (numpy+scipy.fft, workers=None) on one (2^22, 8, 2) c64 block, "
+        "sample": "oracle (numpy+scipy.fft, workers=None) on one full (2^24, 8, 2) c64 block, "
                   "DM 56.77, chirp precomputed; %.2f s" % t1,
         "all_cores": {"value": nsamp / tall / 1e6, "cores": ncores, "seconds": tall},
         "chirp_seconds": t_chirp, "host_cpus": ncores,

@@ -20,7 +20,14 @@ struct ChirpParams {
     int64_t N;
     int N1, N2, nchan;
     float scale;
+    int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
 };
+
+__device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w) {
+    if (perm_w == 0) return e2;
+    const int mw = N2 / perm_w;
+    return e2 / mw + (int64_t)perm_w * (e2 % mw);
+}
 
 __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
     const int64_t total = p.N * p.nchan;
@@ -28,7 +35,7 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / p.N);
         const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t k1 = e / p.N2, k2 = e - k1 * p.N2;
+        const int64_t k1 = e / p.N2, k2 = row_bin(e - k1 * p.N2, p.N2, p.perm_w);
         const int64_t k = k1 + (int64_t)p.N1 * k2;
         const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
         const double f = p.chan_freq[chan] + (double)bin * p.inv_ndt;
@@ -44,13 +51,13 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
 // natural (N, nchan) <-> plan order [chan][k1][k2]; `to_plan` selects the direction.
 __global__ __launch_bounds__(256) void k_chirp_reorder(const cf* __restrict__ src, cf* __restrict__ dst,
                                                        int64_t N, int N1, int N2, int nchan, float scale,
-                                                       int to_plan) {
+                                                       int to_plan, int perm_w) {
     const int64_t total = N * nchan;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / N);
         const int64_t e = d - (int64_t)chan * N;
-        const int64_t k1 = e / N2, k2 = e - k1 * N2;
+        const int64_t k1 = e / N2, k2 = row_bin(e - k1 * N2, N2, perm_w);
         const int64_t k = k1 + (int64_t)N1 * k2;
         const int64_t nat = k * nchan + chan;
         if (to_plan) {

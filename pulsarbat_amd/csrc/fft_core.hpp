@@ -133,10 +133,13 @@ struct Dft<32, DIR> {
 // stage of the remainder.
 constexpr int stage_radix(int M, int NS, int R) { return (M / NS >= R) ? R : (M / NS); }
 // number of stage-twiddle seeds a thread needs for the stages starting at sub-length NS
+// (the last stage's butterflies q = 0..NB-1 share one seed: W_M^{(tau + q M/R) j} = (W_M^tau)^j W_R^{q j},
+//  and W_R^{q j} is a compile-time constant)
+constexpr int stage_seeds(int M, int NS, int R) {
+    return NS <= 1 ? 0 : (NS * stage_radix(M, NS, R) == M ? 1 : R / stage_radix(M, NS, R));
+}
 constexpr int tw_seeds(int M, int NS, int R) {
-    return NS >= M ? 0
-                   : ((NS > 1 ? R / stage_radix(M, NS, R) : 0) +
-                      tw_seeds(M, NS * stage_radix(M, NS, R), R));
+    return NS >= M ? 0 : (stage_seeds(M, NS, R) + tw_seeds(M, NS * stage_radix(M, NS, R), R));
 }
 constexpr int tw_seeds_or1(int M, int R) { return tw_seeds(M, 1, R) > 0 ? tw_seeds(M, 1, R) : 1; }
 
@@ -167,13 +170,14 @@ __device__ __forceinline__ void load_tw_seeds(cf* w, int tau, const cf* __restri
         constexpr int RAD = stage_radix(M, NS, R);
         constexpr int NB = R / RAD;
         if constexpr (NS > 1) {
+            constexpr int NSEED = stage_seeds(M, NS, R);
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
+            for (int q = 0; q < NSEED; ++q) {
                 int jb = tau + q * (M / R);
                 int k = jb & (NS - 1);
                 w[q] = tw[k * (kTwTable / (NS * RAD))];
             }
-            load_tw_seeds<M, NS * RAD, R>(w + NB, tau, tw);
+            load_tw_seeds<M, NS * RAD, R>(w + NSEED, tau, tw);
         } else {
             load_tw_seeds<M, NS * RAD, R>(w, tau, tw);
         }
@@ -226,7 +230,19 @@ __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
 //   w     : seeds from load_tw_seeds<M, 1, R> (forward sign; conjugated here for DIR = +1)
 // fofs must be a multiple of 32 when PS == 1 (row tiles: fofs = f * M).
 // Must be called by all threads of the workgroup (contains barriers).
-template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false>
+// WSYNC = true: the "tile" is private to ONE wavefront (tau = lane); LDS operations of a wave execute
+// in order, so the exchange needs only a compiler-level fence, no workgroup barrier.
+template <bool WSYNC>
+__device__ __forceinline__ void tile_sync() {
+    if constexpr (WSYNC) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false, bool WSYNC = false>
 __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w) {
     if constexpr (NS < M) {
         constexpr int RAD = stage_radix(M, NS, R);
@@ -241,9 +257,13 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
             int jb = tau + q * MR;
             int k = jb & (NS - 1);
             if constexpr (NS > 1) {
-                cf w1 = w[q];
+                cf w1 = w[(LAST && NB > 1) ? 0 : q];
                 if (DIR > 0) w1 = cconj(w1);
                 apply_powers<RAD>(t, w1);
+                if constexpr (LAST && NB > 1) {
+#pragma unroll
+                    for (int j = 1; j < RAD; ++j) t[j] = mul_w32<DIR>(t[j], q * j * (32 / R));
+                }
             }
             Dft<RAD, DIR>::run(t);
             if constexpr (LAST) {
@@ -291,9 +311,9 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 }
                 __syncthreads();
             }
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + stage_seeds(M, NS, R));
         } else if constexpr (!LAST) {
-            __syncthreads();
+            tile_sync<WSYNC>();
             constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
             if constexpr (RLIN) {
                 const cf* rp = lds + lds_phys<PAD>(tau * PS + fofs);
@@ -303,8 +323,8 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
 #pragma unroll
                 for (int i = 0; i < R; ++i) v[i] = lds[lds_phys<PAD>((tau + i * MR) * PS + fofs)];
             }
-            __syncthreads();
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + (NS > 1 ? NB : 0));
+            tile_sync<WSYNC>();
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, WSYNC>(v, lds, tau, fofs, w + stage_seeds(M, NS, R));
         }
     }
 }

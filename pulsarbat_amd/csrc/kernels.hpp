@@ -161,6 +161,7 @@ struct RowParams {
     const cf* tw16k;
     int64_t nrows;     // S * N1
     int N1, npol;
+    int perm_w;        // chirp row order (see ChirpParams::perm_w); 8 selects k_row2
 };
 
 // Persistent, software-pipelined: a workgroup walks over tiles; while tile i is transformed the
@@ -169,7 +170,9 @@ struct RowParams {
 // sets live in VGPRs (64 each) beside the 64 data registers; buffer loads survive the barriers.
 // Tile order: the pols of one (channel, k1) run back to back on the same workgroup so the second
 // one finds the chirp row in L2/MALL instead of HBM.
-template <int M, int R, bool PF>
+// ABL (diagnostic builds only): 0 = product kernel, 1 = no FFTs (memory traffic only),
+// 2 = no chirp loads (constant multiplier), 3 = neither loads nor stores after the first tile
+template <int M, int R, bool PF, int ABL = 0>
 __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     constexpr int FR = kTilePoints / M;  // rows per tile
     constexpr int MR = M / R;
@@ -221,8 +224,9 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         if constexpr (PF) {
             cf c[R];
 #pragma unroll
-            for (int i = 0; i < R; ++i) c[i] = buf_load(rc, voff, i * STEP);
-            fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
+            for (int i = 0; i < R; ++i)
+                c[i] = (ABL == 2 || ABL == 3) ? make_float2(0.999f, 0.001f * i) : buf_load(rc, voff, i * STEP);
+            if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
             for (int i = 0; i < R; ++i) v[i] = cmul(v[i], c[i]);
         } else {
@@ -238,13 +242,15 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         if constexpr (PF) {
             cf nx[R];
 #pragma unroll
-            for (int i = 0; i < R; ++i) nx[i] = buf_load(rdn, voff, i * STEP);
-            fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
+            for (int i = 0; i < R; ++i) nx[i] = (ABL == 3) ? v[i] : buf_load(rdn, voff, i * STEP);
+            if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
+            if (ABL != 3 || !more) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
+                for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
+            }
             if (!more) break;
 #pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = nx[i];
+            for (int i = 0; i < R; ++i) v[i] = (ABL == 3) ? make_float2(v[i].x + nx[i].y, v[i].y) : nx[i];
         } else {
             fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
@@ -253,6 +259,135 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
 #pragma unroll
             for (int i = 0; i < R; ++i) v[i] = buf_load(rdn, voff, i * STEP);
         }
+        t = tn;
+        r0 = rn;
+        rd = rdn;
+    }
+}
+
+// ---- fused row pass, wave-decoupled form (M = 16384 = 8 x 2048) ------------------------------------------
+// k = ka + 8 kb, n = 2048 na + nb.  Forward: radix-8 over na inside each thread (its 32 points
+// tau + 512 i contain na = 0..7 for four values of nb), twiddle W_M^{nb ka}, ONE cross-wave exchange
+// that hands wave `ka` the 2048 points A[ka][.], then every wavefront runs its own 2048-point FFT
+// through a private LDS region with wave-level synchronisation only.  The inverse mirrors it.  Per
+// tile: 4 workgroup barriers instead of 8, and between them the eight waves run decoupled, so one
+// wave's LDS exchange overlaps another's butterflies.  The chirp row is stored in the matching
+// order (position ka*2048 + kb holds bin ka + 8 kb; ChirpParams::perm_w).
+template <bool PF>
+__global__ __launch_bounds__(512) void k_row2(RowParams p) {
+    constexpr int M = 16384, R = 32, MR = 512, MW = 2048;
+    constexpr int STEP = 64 * (int)sizeof(cf);   // a wave's points: lane + 64 i
+    constexpr int STEPT = MR * (int)sizeof(cf);  // a thread's natural points: tau + 512 i
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+
+    const int tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const int voff_t = tau * (int)sizeof(cf);
+    const int voff_w = (wave * MW + lane) * (int)sizeof(cf);
+    const int64_t ntile = p.nrows;
+
+    cf wq[4];  // W_M^{nb}, nb = tau + 512 c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wq[c] = p.tw16k[tau + MR * c];
+    cf w[tw_seeds_or1(MW, R)];
+    load_tw_seeds<MW, 1, R>(w, lane, p.tw16k);
+
+    auto first_row = [&](int64_t t) -> int64_t {
+        if (p.npol > 1) {
+            const int64_t pair = t / p.npol;
+            const int pol = (int)(t - pair * p.npol);
+            const int64_t chan = pair / p.N1, k1 = pair - chan * p.N1;
+            return (chan * p.npol + pol) * (int64_t)p.N1 + k1;
+        }
+        return t;
+    };
+    constexpr uint32_t ROWB = (uint32_t)(M * sizeof(cf));
+
+    int64_t t = blockIdx.x;
+    if (t >= ntile) return;
+    int64_t r0 = first_row(t);
+    rsrc_t rd = make_rsrc(p.data + r0 * M, ROWB);
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff_t, i * STEPT);
+
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < tw_seeds_or1(MW, R); ++i) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(wq[c].x), "+v"(wq[c].y));
+        const int64_t srs = r0 / p.N1;
+        const int k1 = (int)(r0 - srs * p.N1);
+        const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M, ROWB);
+        cf c[PF ? R : 1];
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) c[i] = buf_load(rc, voff_w, i * STEP);
+        }
+
+        // ---- forward: radix-8 over na, twiddle, cross-wave exchange ----
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            cf t8[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) t8[a] = v[cc + 4 * a];
+            Dft<8, -1>::run(t8);
+            apply_powers<8>(t8, wq[cc]);
+#pragma unroll
+            for (int ka = 0; ka < 8; ++ka) lds[ka * MW + tau + MR * cc] = t8[ka];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = lds[wave * MW + lane + 64 * i];
+        __syncthreads();
+        fft_tile<MW, 1, R, -1, 1, true, false, true>(v, lds, lane, wave * MW, w);
+
+        // ---- chirp ----
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], c[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, voff_w, i * STEP));
+        }
+
+        const int64_t tn = t + gridDim.x;
+        const bool more = tn < ntile;
+        const int64_t rn = more ? first_row(tn) : r0;
+        const rsrc_t rdn = more ? make_rsrc(p.data + rn * M, ROWB) : make_rsrc(p.data, 0);
+        cf nx[PF ? R : 1];
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) nx[i] = buf_load(rdn, voff_t, i * STEPT);
+        }
+
+        // ---- inverse: per-wave 2048-point IFFT, cross-wave exchange back, twiddle, radix-8 ----
+        fft_tile<MW, 1, R, +1, 1, true, false, true>(v, lds, lane, wave * MW, w);
+        __syncthreads();  // every wave is done with its private (padded) region
+#pragma unroll
+        for (int i = 0; i < R; ++i) lds[wave * MW + lane + 64 * i] = v[i];
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            cf t8[8];
+#pragma unroll
+            for (int ka = 0; ka < 8; ++ka) t8[ka] = lds[ka * MW + tau + MR * cc];
+            apply_powers<8>(t8, cconj(wq[cc]));
+            Dft<8, +1>::run(t8);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[cc + 4 * a] = t8[a];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) buf_store(rd, voff_t, i * STEPT, v[i]);
+        if (!more) break;
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = nx[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = buf_load(rdn, voff_t, i * STEPT);
+        }
+        __syncthreads();  // the cross buffer is rewritten by the next tile's forward pass
         t = tn;
         r0 = rn;
         rd = rdn;
@@ -288,17 +423,23 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
+    // buffer addressing: wave-uniform descriptors over the whole block, per-lane offset
+    // (tau*S + q)*8, scalar step MR*S*8; invalid lanes get an out-of-range offset (reads 0, writes dropped)
+    const uint32_t in_bytes = (uint32_t)((int64_t)M * p.S * sizeof(cf));
+    const rsrc_t ri = make_rsrc(p.in, in_bytes);
+    const int oob = 0x7ffffff0;
+    const int voff = valid ? (int)((tau * (int64_t)p.S + qq) * sizeof(cf)) : oob;
+    const int step = MR * p.S * (int)sizeof(cf);
     cf v[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        int64_t row = tau + i * MR;
-        v[i] = valid ? p.in[row * p.S + qq] : make_float2(0.f, 0.f);
-    }
+    for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff, i * step);
+
     if (p.chirp) {
-        const cf* crow = p.chirp + (qq / p.npol) * (int64_t)M;
+        const rsrc_t rc = make_rsrc(p.chirp + (qq / p.npol) * (int64_t)M, (uint32_t)(M * sizeof(cf)));
+        const int coff = tau * (int)sizeof(cf);
         fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = cmul(v[i], crow[tau + i * MR]);
+        for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, coff, i * MR * (int)sizeof(cf)));
         fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
     } else if (p.dir < 0) {
         fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
@@ -307,11 +448,15 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i] = make_float2(v[i].x * p.scale, v[i].y * p.scale);
     }
+    // output rows [crop_start, crop_stop) -> out row (row - crop_start)
+    const int64_t nout_rows = p.crop_stop - p.crop_start;
+    const rsrc_t ro = make_rsrc(p.out, (uint32_t)(nout_rows * p.S * sizeof(cf)));
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        int64_t row = tau + i * MR;
-        if (valid && row >= p.crop_start && row < p.crop_stop)
-            p.out[(row - p.crop_start) * p.S + qq] = v[i];
+        const int64_t row = tau + i * MR;
+        const bool keep = valid && row >= p.crop_start && row < p.crop_stop;
+        const int off = keep ? (int)(((row - p.crop_start) * p.S + qq) * sizeof(cf)) : oob;
+        buf_store(ro, off, 0, v[i]);
     }
 }
 

@@ -56,6 +56,7 @@ struct pbh_plan {
     int variant = PBH_VARIANT_AUTO;
     hipStream_t stream = nullptr;
     bool has_chirp = false;
+    int perm_w = 0;  // chirp row order: 0 natural, 8 = wave-decoupled row kernel (k_row2)
 
     cf* work = nullptr;      // planar workspace, S * N
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
@@ -148,10 +149,15 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (prm.nrows + FR - 1) / FR;
     if (tiles > row_grid()) tiles = row_grid();
-    static int mode = [] { const char* e = getenv("PBH_ROW_MODE"); return e ? atoi(e) : 0; }();
-    if (M == 16384 && mode == 1) return launch_tile_kernel(k_row<16384, 32, false>, prm, tiles, kTilePoints / 32, st);
-    if (M == 16384 && mode == 2) return launch_tile_kernel(k_row<16384, 16, false>, prm, tiles, kTilePoints / 16, st);
-    if (M == 16384 && mode == 3) return launch_tile_kernel(k_row<16384, 16, true>, prm, tiles, kTilePoints / 16, st);
+#ifdef PBH_DIAGNOSTIC  // ablation builds: -DPBH_DIAGNOSTIC, then PBH_ROW_ABL=1|2|3
+    static int abl = [] { const char* e = getenv("PBH_ROW_ABL"); return e ? atoi(e) : 0; }();
+    if (M == 16384 && abl == 1) return launch_tile_kernel(k_row<16384, 32, true, 1>, prm, tiles, 512, st);
+    if (M == 16384 && abl == 2) return launch_tile_kernel(k_row<16384, 32, true, 2>, prm, tiles, 512, st);
+    if (M == 16384 && abl == 3) return launch_tile_kernel(k_row<16384, 32, true, 3>, prm, tiles, 512, st);
+#endif
+    if (prm.perm_w == 8) {
+        return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
+    }
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, 32, true>, prm, tiles, kTilePoints / 32, st);
         X(1024) X(2048) X(4096) X(8192) X(16384)
@@ -162,6 +168,8 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
 
 static int launch_small(int M, const SmallParams& prm, hipStream_t st) {
     const int F = kTilePoints / M;
+    if ((int64_t)M * prm.S * (int64_t)sizeof(cf) > 0x7fffffffLL)
+        return fail(PBH_ERR_UNSUPPORTED, "single-tile block larger than 2 GiB (too many series)");
     const int64_t tiles = ((int64_t)prm.S + F - 1) / F;
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_small<m, 32>, prm, tiles, kTilePoints / 32, st);
@@ -252,7 +260,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
-        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
@@ -277,7 +285,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         const int sb = 4, lo = block_lane_order();
         ColParams c1{in, work, inter, planar, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k, 0, p->N, 0};
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
-        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol};
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         ColParams c3{work, out, planar, inter, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k,
                      p->start, p->stop, p->start * S};
@@ -355,6 +363,11 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
         const int l2 = (n - 5 < kTileLog2) ? n - 5 : kTileLog2;
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
+    }
+    {
+        const char* e = getenv("PBH_ROW2");
+        const bool want = e ? atoi(e) != 0 : false;
+        p->perm_w = (want && p->N1 > 1 && p->N2 == 16384) ? 8 : 0;
     }
     int rc = PBH_OK;
     auto bail = [&](int code) {
@@ -454,7 +467,7 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     HIPCHECK(hipSetDevice(p->device));
     HIPCHECK(hipMemcpyAsync(p->chan_freq, chan_freq_hz, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, coeff_hz, 1.0 / ((double)p->N * dt_s), 1.0 / ref_freq_hz,
-                   p->N, p->N1, p->N2, p->nchan, inv_n(p)};
+                   p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
     hipLaunchKernelGGL(k_chirp, dim3(2048), dim3(256), 0, p->stream, cp);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));  // chan_freq_hz is a borrowed host buffer
@@ -473,7 +486,7 @@ int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
         src = (const cf*)p->stage_in;
     }
     hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, p->chirp, p->N, p->N1, p->N2,
-                       p->nchan, inv_n(p), 1);
+                       p->nchan, inv_n(p), 1, p->perm_w);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
@@ -491,7 +504,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
         dst = (cf*)p->stage_out;
     }
     hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const cf*)p->chirp, dst, p->N, p->N1,
-                       p->N2, p->nchan, (float)p->N, 0);
+                       p->N2, p->nchan, (float)p->N, 0, p->perm_w);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
         HIPCHECK(hipMemcpyAsync(chirp_c64, dst, bytes, hipMemcpyDeviceToHost, p->stream));
@@ -523,7 +536,7 @@ int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t ns
     if (e == hipSuccess) {
         // natural order, any nsample (not only powers of two): N1 = 1, N2 = N
         ChirpParams cp{dbuf, dfreq, coeff_hz, 1.0 / ((double)nsample * dt_s), 1.0 / ref_freq_hz,
-                       nsample, 1, (int)nsample, 1, 1.0f};
+                       nsample, 1, (int)nsample, 1, 1.0f, 0};
         hipLaunchKernelGGL(k_chirp, dim3(1024), dim3(256), 0, st, cp);
         e = hipGetLastError();
     }
