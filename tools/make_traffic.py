@@ -13,18 +13,19 @@ def step(kname):
         if k.startswith(a):
             return b
     return None
+# per kernel name: mean over dispatches; a step's traffic is the SUM over the kernels it launches
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            s = step(r["Kernel_Name"])
-            if s:
-                acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {}
-for s, c in acc.items():
+            if step(r["Kernel_Name"]):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = collections.defaultdict(float)
+for kname, c in acc.items():
     fetch = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))
     write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
-    res[s] = (2.0 * fetch + write) * 1024.0
+    res[step(kname)] += (2.0 * fetch + write) * 1024.0
+res = dict(res)
 res["_source"] = os.path.basename(root) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
