@@ -89,6 +89,12 @@ def main():
     ap.add_argument("--dm", type=float, default=DM, help="(debug) dispersion measure")
     args = ap.parse_args()
 
+    # keep stdout to the one JSON line: RCCL (a C library) prints its banner/warnings to fd 1, so
+    # fd 1 is pointed at stderr for the run and the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -99,7 +105,7 @@ def main():
         if world == 1 and args.gpus > 1:
             log(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
             sys.exit(2)
-    distributed = world > 1
+    distributed = world > 1 or "RANK" in os.environ  # under torchrun: exercise RCCL even with one rank
     torch.cuda.set_device(local_rank)
     if distributed:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -204,7 +210,7 @@ def main():
                 result["cpu_baseline"] = cpu_baseline()
             except Exception as exc:  # the baseline is a reported extra; never lose the GPU line
                 result["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
