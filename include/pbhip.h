@@ -35,7 +35,7 @@ typedef struct pbh_plan pbh_plan;
 typedef enum {
     PBH_OK = 0,
     PBH_ERR_INVALID = -1,     /* bad argument (NULL, non-positive size, bad enum)            */
-    PBH_ERR_UNSUPPORTED = -2, /* valid request this build cannot serve (e.g. nsample not 2^k) */
+    PBH_ERR_UNSUPPORTED = -2, /* valid request this build cannot serve (e.g. complex128 data)    */
     PBH_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString)    */
     PBH_ERR_NOMEM = -4,       /* device or host allocation failed                             */
     PBH_ERR_STATE = -5        /* call sequence error (e.g. dedisperse before a chirp is set)  */
@@ -73,7 +73,7 @@ typedef struct {
     double  alg_bytes_per_sample; /* SURVEY.md 8(d) accounting figure for this plan           */
 } pbh_plan_info_t;
 
-#define PBH_MAX_KERNELS 8
+#define PBH_MAX_KERNELS 16
 
 /* ---- library ---------------------------------------------------------------------------- */
 int pbh_device_count(void);

@@ -19,7 +19,7 @@ __all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detec
 HOST, DEVICE = 0, 1
 DETECT_MODES = {"intensity": 0, "I": 1, "stokes_i": 1, "linear": 2, "circular": 3}
 VARIANTS = {"auto": 0, "planar5": 1, "direct3": 2, "block3": 3}
-MAX_KERNELS = 8
+MAX_KERNELS = 16
 
 
 class HipError(RuntimeError):

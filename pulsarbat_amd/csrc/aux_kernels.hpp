@@ -287,6 +287,74 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
     }
 }
 
+// ---- Bluestein (arbitrary nsample) ---------------------------------------------------------------------------
+// W_N^{nk} = b[n] b[k] conj(b[k-n]) with b[n] = exp(-i pi n^2 / N), so
+//   FFT_N(x)[k] = b[k] * ((x b) (*) conj(b))[k]
+// and the linear convolution (*) is a circular one of any length L >= 2N-1: the power-of-two
+// pipeline IFFT_L(FFT_L(a) * C) with C = FFT_L(wrapped conj(b)) in place of the chirp.  The whole
+// dedispersion y = IFFT_N(FFT_N(x) H) becomes
+//   a1 = x b (zero-padded)      -> conv1 = pipeline(a1)
+//   a2 = conj(conv1 * H/N)      -> conv2 = pipeline(a2)     (|b| = 1 cancels the b[k] factors)
+//   y  = conj(b * conv2)
+// n^2 mod 2N is formed in 64-bit integers (n < 2^27), the angle in float64.
+__device__ __forceinline__ cf bs_chirp(int64_t n, int64_t N, double sign) {
+    const int64_t r = (n * n) % (2 * N);
+    double s, c;
+    sincospi((double)r / (double)N, &s, &c);
+    return make_float2((float)c, (float)(sign * s));
+}
+
+// b[n] = exp(-i pi n^2/N), n < N
+__global__ __launch_bounds__(256) void k_bs_table(cf* __restrict__ b, int64_t N) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        b[n] = bs_chirp(n, N, -1.0);
+}
+
+// wrapped convolution kernel conj(b)[m] for |m| < N on a ring of L points, times `scale`
+__global__ __launch_bounds__(256) void k_bs_kernel(cf* __restrict__ c, int64_t N, int64_t L, float scale) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < L; m += (int64_t)gridDim.x * blockDim.x) {
+        cf v = make_float2(0.f, 0.f);
+        if (m < N) v = bs_chirp(m, N, +1.0);
+        else if (m > L - N) v = bs_chirp(L - m, N, +1.0);
+        c[m] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// a[(n, s)] = n < N ? x[(n, s)] * b[n] : 0        (L rows of S series)
+__global__ __launch_bounds__(256) void k_bs_pre(const cf* __restrict__ x, const cf* __restrict__ b,
+                                                cf* __restrict__ a, int64_t N, int64_t L, int S) {
+    const int64_t total = L * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / S;
+        cf v = make_float2(0.f, 0.f);
+        if (n < N) v = cmul(x[e], b[n]);
+        a[e] = v;
+    }
+}
+
+// a[(k, s)] = k < N ? conj(conv[(k, s)] * H[chan(s)][k]) : 0
+__global__ __launch_bounds__(256) void k_bs_mid(const cf* __restrict__ conv, const cf* __restrict__ H,
+                                                cf* __restrict__ a, int64_t N, int64_t L, int S, int npol) {
+    const int64_t total = L * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / S;
+        const int s = (int)(e - k * S);
+        cf v = make_float2(0.f, 0.f);
+        if (k < N) v = cconj(cmul(conv[e], H[(int64_t)(s / npol) * N + k]));
+        a[e] = v;
+    }
+}
+
+// out[(n - start, s)] = conj(b[n] * conv[(n, s)]),  start <= n < stop
+__global__ __launch_bounds__(256) void k_bs_post(const cf* __restrict__ conv, const cf* __restrict__ b,
+                                                 cf* __restrict__ out, int64_t start, int64_t stop, int S) {
+    const int64_t total = (stop - start) * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = start + e / S;
+        out[e] = cconj(cmul(conv[start * S + e], b[n]));
+    }
+}
+
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -265,6 +265,28 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     }
 }
 
+// ---- forward-only row FFT, in place (builds the Bluestein kernel's spectrum in plan order) -------------------
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_rowfft(cf* data, const cf* tw16k, int64_t nrows) {
+    constexpr int FR = kTilePoints / M, MR = M / R, STEP = MR * (int)sizeof(cf);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int tau = tid % MR, f = tid / MR;
+    const int64_t r0 = (int64_t)blockIdx.x * FR;
+    const int64_t left = nrows - r0;
+    const rsrc_t rd = make_rsrc(data + r0 * M, (uint32_t)((left < FR ? left : FR) * (int64_t)M * sizeof(cf)));
+    const int voff = (f * M + tau) * (int)sizeof(cf);
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, tw16k);
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
+    fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
+#pragma unroll
+    for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
+}
+
 // ---- fused row pass, wave-decoupled form (M = 16384 = 8 x 2048) ------------------------------------------
 // k = ka + 8 kb, n = 2048 na + nb.  Forward: radix-8 over na inside each thread (its 32 points
 // tau + 512 i contain na = 0..7 for four values of nb), twiddle W_M^{nb ka}, ONE cross-wave exchange

@@ -65,6 +65,12 @@ struct pbh_plan {
     double2* tw_lo = nullptr;
     int tw_shift = 0;
     double* chan_freq = nullptr;
+    // Bluestein (nsample not a power of two, or < 32): two runs of a power-of-two sub-plan
+    int64_t bsL = 0;            // ring length, power of two >= 2N-1; 0 = not a Bluestein plan
+    pbh_plan* sub = nullptr;    // (bsL, 1 chan, S "pols") plan whose chirp is FFT_L(wrapped conj b)/L
+    cf* bs_b = nullptr;         // b[n] = exp(-i pi n^2/N)
+    cf* bs_a = nullptr;         // (bsL, S) pipeline input
+    cf* bs_conv = nullptr;      // (bsL, S) pipeline output
     void* stage_in = nullptr;   // device staging for host inputs
     void* stage_out = nullptr;  // device staging for host outputs
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
@@ -137,6 +143,8 @@ static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
     prm.ntile = (int)ntile;
     // (a split re/im exchange variant, k_col<..., true>, gives two workgroups per CU; it measured
     //  slower -- 1.14 vs 0.98 ms -- because the 128-VGPR cap spills: not instantiated)
+    // (cache-policy experiments on the partial-line variants: non-temporal loads/stores 2-3x slower --
+    //  they defeat the L2 merging --, sc1 loads -5 % at best)
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32, false>, prm, ntile, kTilePoints / 32, st);
         FOR_ALL_M(X)
@@ -239,6 +247,33 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail()) {
     std::vector<Step> steps;
     const int S = p->S;
+    if (p->bsL) {
+        const int64_t N = p->N, L = p->bsL, start = p->start, stop = p->stop;
+        const int npol = p->npol;
+        cf *a = p->bs_a, *conv = p->bs_conv;
+        const cf *b = p->bs_b, *H = p->chirp;
+        auto grid = [](int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
+        steps.push_back({"k_bs_pre", [=](hipStream_t st) {
+            hipLaunchKernelGGL(k_bs_pre, dim3(grid(L * S)), dim3(256), 0, st, in, b, a, N, L, S);
+            HIPCHECK(hipGetLastError());
+            return (int)PBH_OK;
+        }});
+        for (auto& s : build_steps(p->sub, a, conv)) steps.push_back(s);
+        steps.push_back({"k_bs_mid", [=](hipStream_t st) {
+            hipLaunchKernelGGL(k_bs_mid, dim3(grid(L * S)), dim3(256), 0, st, (const cf*)conv, H, a, N, L, S, npol);
+            HIPCHECK(hipGetLastError());
+            return (int)PBH_OK;
+        }});
+        for (auto& s : build_steps(p->sub, a, conv)) steps.push_back(s);
+        steps.push_back({"k_bs_post", [=](hipStream_t st) {
+            if (stop <= start) return (int)PBH_OK;
+            hipLaunchKernelGGL(k_bs_post, dim3(grid((stop - start) * S)), dim3(256), 0, st, (const cf*)conv, b, out,
+                               start, stop, S);
+            HIPCHECK(hipGetLastError());
+            return (int)PBH_OK;
+        }});
+        return steps;
+    }
     if (p->N1 == 1) {
         SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, 1.0f};
         const int M = (int)p->N;
@@ -317,6 +352,66 @@ static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
     return PBH_OK;
 }
 
+static int launch_rowfft(int M, cf* data, const cf* tw, int64_t nrows, hipStream_t st) {
+    const int FR = kTilePoints / M;
+    const int64_t tiles = (nrows + FR - 1) / FR;
+    struct Args { cf* data; const cf* tw; int64_t nrows; };
+    switch (M) {
+#define X(m)                                                                                               \
+    case m: {                                                                                              \
+        auto kern = k_rowfft<m, 32>;                                                                       \
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                     lds_tile_bytes<true>()));                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kTilePoints / 32), lds_tile_bytes<true>(), st, \
+                           data, tw, nrows);                                                               \
+        break;                                                                                             \
+    }
+        X(1024) X(2048) X(4096) X(8192) X(16384)
+#undef X
+        default: return fail(PBH_ERR_UNSUPPORTED, "row FFT length " + std::to_string(M));
+    }
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+extern "C" int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
+                               int64_t crop_start, int64_t crop_stop);
+
+// Bluestein set-up: sub-plan over the ring length, b table, and the spectrum of the wrapped kernel
+// conj(b) written straight into the sub-plan's chirp buffer in plan order (column pass + forward
+// row pass leave bin k1 + N1 k2 at position k1*N2 + k2, which is the chirp layout).
+static int setup_bluestein(pbh_plan* p) {
+    const int64_t N = p->N, L = p->bsL;
+    PBHCHECK(pbh_plan_create(&p->sub, p->device, L, 1, p->S, PBH_C64, 0, L));
+    pbh_plan* q = p->sub;
+    q->perm_w = 0;  // its "chirp" is produced below by a forward FFT, i.e. in natural plan order
+    p->owned_bytes += q->owned_bytes;
+    PBHCHECK(dev_alloc(p, (void**)&p->bs_b, sizeof(cf) * (size_t)N));
+    PBHCHECK(dev_alloc(p, (void**)&p->bs_a, sizeof(cf) * (size_t)L * p->S));
+    PBHCHECK(dev_alloc(p, (void**)&p->bs_conv, sizeof(cf) * (size_t)L * p->S));
+    hipStream_t st = nullptr;
+    hipLaunchKernelGGL(k_bs_table, dim3(1024), dim3(256), 0, st, p->bs_b, N);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_bs_kernel, dim3(2048), dim3(256), 0, st, q->chirp, N, L, (float)(1.0 / (double)L));
+    HIPCHECK(hipGetLastError());
+    if (q->N1 == 1) {
+        // single tile: forward FFT of one series, out of place through the (still unused) bs_a buffer
+        HIPCHECK(hipMemcpyAsync(p->bs_a, q->chirp, sizeof(cf) * (size_t)L, hipMemcpyDeviceToDevice, st));
+        SmallParams sp{p->bs_a, q->chirp, nullptr, q->tw16k, 1, 1, 0, L, -1, 1.0f};
+        PBHCHECK(launch_small((int)L, sp, st));
+    } else {
+        BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
+        ColSide planar{LAYOUT_PLANAR, L, q->N2};
+        ColParams c1{q->chirp, q->chirp, planar, planar, LAYOUT_PLANAR, 0, 0, 1, q->N2, (int64_t)q->N2, 0, tw,
+                     q->tw16k, 0, L, 0};
+        PBHCHECK(launch_col<OP_FWD_TW>(q->N1, c1, st));
+        PBHCHECK(launch_rowfft(q->N2, q->chirp, q->tw16k, q->N1, st));
+    }
+    HIPCHECK(hipStreamSynchronize(st));
+    q->has_chirp = true;
+    return PBH_OK;
+}
+
 // ================================================ C ABI ==========================================================
 extern "C" {
 
@@ -336,9 +431,10 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
     *out = nullptr;
     if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
     if (dtype != PBH_C64) return fail(PBH_ERR_UNSUPPORTED, "only complex64 is implemented");
-    if (!is_pow2(nsample) || nsample < 32 || nsample > (1LL << 28))
-        return fail(PBH_ERR_UNSUPPORTED,
-                    "nsample must be a power of two in [32, 2^28] (got " + std::to_string(nsample) + ")");
+    const bool pow2 = is_pow2(nsample) && nsample >= 32;
+    if (nsample < 2 || nsample > (1LL << 28) || (!pow2 && nsample > (1LL << 27)))
+        return fail(PBH_ERR_UNSUPPORTED, "nsample must be in [2, 2^28] (powers of two) or [2, 2^27] (other lengths); got " +
+                                             std::to_string(nsample));
     if (crop_start < 0 || crop_start > nsample) return fail(PBH_ERR_INVALID, "crop_start out of range");
     if (crop_stop > nsample) return fail(PBH_ERR_INVALID, "crop_stop out of range");
     int ndev = pbh_device_count();
@@ -356,7 +452,13 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
     p->start = crop_start;
     p->stop = crop_stop < crop_start ? crop_start : crop_stop;  // empty result if the crop is negative
     const int n = ilog2(nsample);
-    if (n <= kTileLog2) {
+    if (!pow2) {
+        p->N1 = 1;  // natural-order chirp H/N; the transforms run in the power-of-two sub-plan
+        p->N2 = (int)nsample;
+        int64_t L = 32;
+        while (L < 2 * nsample - 1) L <<= 1;
+        p->bsL = L;
+    } else if (n <= kTileLog2) {
         p->N1 = 1;
         p->N2 = (int)nsample;
     } else {
@@ -407,6 +509,9 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
             return bail(fail(PBH_ERR_HIP, "hipMemcpy(twiddle tables) failed"));
         if ((rc = dev_alloc(p, (void**)&p->work, sizeof(cf) * (size_t)p->S * nsample)) != PBH_OK) return bail(rc);
     }
+    if (p->bsL) {
+        if ((rc = setup_bluestein(p)) != PBH_OK) return bail(rc);
+    }
     *out = p;
     return PBH_OK;
 }
@@ -414,7 +519,9 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
 int pbh_plan_destroy(pbh_plan* p) {
     if (!p) return PBH_OK;
     hipSetDevice(p->device);
-    void* ptrs[] = {p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out};
+    if (p->sub) pbh_plan_destroy(p->sub);
+    void* ptrs[] = {p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out,
+                    p->bs_b, p->bs_a, p->bs_conv};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete p;
@@ -451,6 +558,11 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->n2 = p->N2;
     info->variant = resolved_variant(p);
     info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3);
+    if (p->bsL) {
+        pbh_plan_info_t sub;
+        pbh_plan_info(p->sub, &sub);
+        info->nkernel = 3 + 2 * sub.nkernel;
+    }
     info->workspace_bytes = p->owned_bytes;
     // 4 passes * 16 B + chirp 8/npol B for multi-pass transforms; one read + one write
     // + chirp for a transform that fits one tile.

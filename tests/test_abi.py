@@ -38,8 +38,9 @@ def test_argument_validation_without_gpu():
     lib = _hip.lib()
     h = ctypes.c_void_p()
     assert lib.pbh_plan_create(None, 0, 1024, 1, 1, 0, 0, 1024) == -1
-    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1000, 1, 1, 0, 0, 1000) == -2
-    assert b"power of two" in lib.pbh_last_error()
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1, 1, 1, 0, 0, 1) == -2
+    assert b"nsample" in lib.pbh_last_error()
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, (1 << 28) + 2, 1, 1, 0, 0, 4) == -2
     assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 0, 1, 0, 0, 1024) == -1
     assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 7, 0, 1024) == -2
     assert lib.pbh_plan_destroy(None) == 0

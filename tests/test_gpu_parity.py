@@ -237,11 +237,27 @@ def test_fft_dispatch_device():
         pb.fft.rfft(d)
 
 
-def test_errors():
-    x = orc.synthetic_block((1000, 2), 1)  # not a power of two
+@pytest.mark.parametrize("shape,dm", [((1000, 2), 1.0), ((16, 3), 0.001), ((6, 1), 0.0), ((8190, 4, 2), 10.0),
+                                      ((100000, 2, 2), 20.0), ((98304, 2), 20.0), ((65537, 1), 5.0),
+                                      ((250047, 3, 2), 30.0), (((1 << 20) + 1, 1, 2), 40.0)])
+def test_arbitrary_lengths(shape, dm):
+    """nsample that is not a power of two (the reference takes any length through pocketfft):
+    Bluestein over the power-of-two pipeline."""
+    check(tuple(shape), dm, 1e6, 1e9, seed=7)
+
+
+def test_arbitrary_length_stream_and_detect():
+    shape, dm = (50000, 2, 2), 10.0
+    x = orc.synthetic_block(shape, 3)
     z = make_signal(x, 1e6, 1e9)
-    with pytest.raises(NotImplementedError):
-        pb.coherent_dedispersion(z, pb.DM(1.0))
+    got, start = pb.dedisperse_detect(z, pb.DM(dm), mode="linear", nscrunch=10)
+    yr, s0, _ = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    want = orc.scrunch(orc.to_stokes(yr, "linear"), 10)
+    assert start == s0 and got.shape == want.shape
+    assert np.abs(got - want).max() < 3e-5 * np.abs(want).max()
+
+
+def test_errors():
     z128 = make_signal(orc.synthetic_block((1024, 2), 1).astype(np.complex128), 1e6, 1e9)
     with pytest.raises(NotImplementedError):
         pb.coherent_dedispersion(z128, pb.DM(1.0))
