@@ -11,8 +11,9 @@
  *  - plain C: pointers and sizes only, no C++/torch types.
  *  - every function returns PBH_OK (0) or a negative pbh_status; it never throws and never
  *    aborts.  pbh_last_error() returns a thread-local message for the last failure.
- *  - arrays are C-contiguous, time (sample) axis first: (nsample, nchan, npol) complex64
- *    exactly as BasebandSignal.data (pulsarbat/core.py:704-764).
+ *  - arrays are C-contiguous, time (sample) axis first: (nsample, nchan, npol) complex64 or
+ *    complex128 (the plan's dtype) exactly as BasebandSignal.data (pulsarbat/core.py:704-764);
+ *    parameter names say c64/f32 for the common case.
  *  - a pointer's residency is given by a pbh_loc argument.  Host buffers are borrowed for
  *    the duration of the call.  Device buffers must live on the plan's device.
  *  - a plan is not re-entrant (one in-flight call per plan); distinct plans may be used from
@@ -43,7 +44,11 @@ typedef enum {
 
 typedef enum { PBH_HOST = 0, PBH_DEVICE = 1 } pbh_loc;
 
-typedef enum { PBH_C64 = 0 } pbh_dtype; /* complex64 only (float32 arithmetic, as scipy.fft on c64) */
+/* complex64: float32 arithmetic; complex128: float64 arithmetic -- as scipy.fft does for each
+ * (dtype in = dtype out: reference tests/test_fft.py:53-54; both accepted: pulsarbat/core.py:742).
+ * Detection outputs follow: float32 / float64 (tests/test_radio_signal.py:142-172).  The chirp is
+ * complex64 for both (the reference rounds it: dedispersion.py:23).                              */
+typedef enum { PBH_C64 = 0, PBH_C128 = 1 } pbh_dtype;
 
 /* Detection modes (pulsarbat/core.py:766-774, 930-966). Output float32. */
 typedef enum {
@@ -128,12 +133,12 @@ int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsa
                           int64_t* nchunk, float* ms_total);
 
 /* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
-int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, int64_t nsample,
+int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nsample,
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);
 
 /* Backs pb.fft.fft / pb.fft.ifft for device arrays (pulsarbat/fft.py:30-48 -> scipy.fft.fft/ifft,
  * norm=None): c2c along axis 0 of a C-contiguous (n, batch) c64 array.                              */
-int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64, int64_t n,
+int pbh_fft_c2c(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t n,
                 int64_t batch, int inverse, int in_loc, int out_loc);
 
 /* ---- measurement --------------------------------------------------------------------------------- */

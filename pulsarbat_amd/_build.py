@@ -11,8 +11,9 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpbhip.so")
-SOURCES = ["pbhip.hip"]
-HEADERS = ["fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", os.path.join("..", "..", "include", "pbhip.h")]
+SOURCES = ["pbhip.hip", "pbhip_api.cpp"]
+HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp",
+           os.path.join("..", "..", "include", "pbhip.h")]
 ARCH = "gfx950"
 
 
@@ -35,14 +36,27 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     # -fno-slp-vectorize: v_pk_*_f32 has no rate advantage on gfx950 and its even-aligned register
-    # pairs inflate VGPR pressure in the fully unrolled butterflies
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-           "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
-    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    # pairs inflate VGPR pressure in the fully unrolled butterflies.
+    # pbhip.hip is compiled twice: float32 (pbh32_*) and float64 (-DPBH_F64, pbh64_*); pbhip_api.cpp
+    # owns the public pbh_* symbols and dispatches on the plan's dtype.
+    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
+    jobs = [("pbhip32.o", common + ["-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
+            ("pbhip64.o", common + ["-DPBH_F64", "-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
+            ("pbhip_api.o", common + ["-x", "hip", "-c", "pbhip_api.cpp"])]
+    procs = [(obj, subprocess.Popen(cmd + ["-o", obj], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                    text=True)) for obj, cmd in jobs]
+    logs = []
+    for obj, pr in procs:
+        _, err = pr.communicate()
+        logs.append(f"==== {obj}\n{err}")
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {obj}:\n" + err[-4000:])
     with open(os.path.join(CSRC, "build.log"), "w") as fh:
-        fh.write(res.stderr)
+        fh.write("\n".join(logs))
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + [o for o, _ in jobs]
+    res = subprocess.run(link, cwd=CSRC, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+        raise RuntimeError("link failed:\n" + res.stderr[-4000:])
     os.replace(LIB + ".tmp", LIB)
     if verbose:
         print("built", LIB)

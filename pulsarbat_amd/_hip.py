@@ -17,6 +17,16 @@ __all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detec
            "chirp_function", "copy_bench"]
 
 HOST, DEVICE = 0, 1
+DTYPES = {np.dtype(np.complex64): 0, np.dtype(np.complex128): 1}   # pbh_dtype
+REAL_OF = {np.dtype(np.complex64): np.dtype(np.float32), np.dtype(np.complex128): np.dtype(np.float64)}
+
+
+def _dtype_code(dt):
+    try:
+        return DTYPES[np.dtype(dt)]
+    except KeyError:
+        raise TypeError(f"the HIP path takes complex64 or complex128 data, got {np.dtype(dt)}")
+
 DETECT_MODES = {"intensity": 0, "I": 1, "stokes_i": 1, "linear": 2, "circular": 3}
 VARIANTS = {"auto": 0, "planar5": 1, "direct3": 2, "block3": 3}
 MAX_KERNELS = 16
@@ -58,9 +68,9 @@ SIGNATURES = {
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_float)]),
-    "pbh_detect": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
-                             C.c_int, C.c_int, C.c_int]),
-    "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+    "pbh_detect": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                               C.c_int, C.c_int]),
     "pbh_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
@@ -143,12 +153,14 @@ class Plan:
     """One (nsample, nchan, npol) block geometry + chirp on one device (pbh_plan)."""
 
     def __init__(self, nsample, nchan, npol, crop_start, crop_stop, device=0, variant="auto",
-                 use_torch_stream=True):
+                 use_torch_stream=True, dtype=np.complex64):
         _require_device()
         self._h = C.c_void_p()
         self.device = int(device)
-        _check(lib().pbh_plan_create(C.byref(self._h), self.device, int(nsample), int(nchan), int(npol), 0,
-                                     int(crop_start), int(crop_stop)))
+        self.dtype = np.dtype(dtype)
+        self.real_dtype = REAL_OF[self.dtype] if self.dtype in REAL_OF else None
+        _check(lib().pbh_plan_create(C.byref(self._h), self.device, int(nsample), int(nchan), int(npol),
+                                     _dtype_code(self.dtype), int(crop_start), int(crop_stop)))
         self.nsample, self.nchan, self.npol = int(nsample), int(nchan), int(npol)
         self.crop_start, self.crop_stop = int(crop_start), max(int(crop_stop), int(crop_start))
         self._use_torch_stream = use_torch_stream
@@ -209,8 +221,8 @@ class Plan:
         if tuple(x.shape[:1]) != (self.nsample,) or int(np.prod(x.shape[1:])) != self.nchan * self.npol:
             raise ValueError(f"input shape {tuple(x.shape)} does not match plan "
                              f"({self.nsample}, {self.nchan}, {self.npol})")
-        if x.dtype != np.complex64:
-            raise TypeError("input must be complex64")
+        if x.dtype != self.dtype:
+            raise TypeError(f"input must be {self.dtype} for this plan")
 
     def dedisperse(self, x, out=None):
         """x: (nsample, nchan, npol) c64 numpy or DeviceArray -> (stop-start, ...) same container."""
@@ -220,9 +232,9 @@ class Plan:
         oshape = (self.nout,) + tuple(x.shape[1:])
         if out is None:
             if isinstance(x, DeviceArray):
-                out = DeviceArray.empty(oshape, np.complex64, device=self.device)
+                out = DeviceArray.empty(oshape, self.dtype, device=self.device)
             else:
-                out = np.empty(oshape, dtype=np.complex64)
+                out = np.empty(oshape, dtype=self.dtype)
         pin, lin = _ptr_loc(x)
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse(self._h, pin, pout, lin, lout))
@@ -237,9 +249,9 @@ class Plan:
         oshape = (self.nout // int(nscrunch),) + tail
         if out is None:
             if isinstance(x, DeviceArray):
-                out = DeviceArray.empty(oshape, np.float32, device=self.device)
+                out = DeviceArray.empty(oshape, self.real_dtype, device=self.device)
             else:
-                out = np.empty(oshape, dtype=np.float32)
+                out = np.empty(oshape, dtype=self.real_dtype)
         pin, lin = _ptr_loc(x)
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))
@@ -247,8 +259,8 @@ class Plan:
 
     def dedisperse_stream(self, x_host, out=None):
         """Overlap-save over a long host block: (total, nchan, npol) c64 -> (nchunk*hop, ...), plus ms."""
-        if not isinstance(x_host, np.ndarray) or x_host.dtype != np.complex64 or not x_host.flags.c_contiguous:
-            raise TypeError("dedisperse_stream needs a C-contiguous complex64 numpy array")
+        if not isinstance(x_host, np.ndarray) or x_host.dtype != self.dtype or not x_host.flags.c_contiguous:
+            raise TypeError(f"dedisperse_stream needs a C-contiguous {self.dtype} numpy array")
         if int(np.prod(x_host.shape[1:])) != self.nchan * self.npol:
             raise ValueError("sample shape does not match the plan")
         hop = self.nout
@@ -256,7 +268,7 @@ class Plan:
             raise ValueError("empty valid region or input shorter than one chunk")
         nchunk = (x_host.shape[0] - self.nsample) // hop + 1
         if out is None:
-            out = np.empty((nchunk * hop,) + tuple(x_host.shape[1:]), dtype=np.complex64)
+            out = np.empty((nchunk * hop,) + tuple(x_host.shape[1:]), dtype=self.dtype)
         self._sync_stream()
         n, ms = C.c_int64(), C.c_float()
         _check(lib().pbh_dedisperse_stream(self._h, C.c_void_p(x_host.ctypes.data), int(x_host.shape[0]),
@@ -282,8 +294,8 @@ def detect(x, mode="intensity", nscrunch=1):
     m = DETECT_MODES[mode]
     n, nchan = x.shape[0], x.shape[1]
     npol = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
-    if x.dtype != np.complex64:
-        raise TypeError("detect needs complex64 data")
+    code = _dtype_code(x.dtype)
+    rdt = REAL_OF[np.dtype(x.dtype)]
     if m == 0:
         oshape = (n // nscrunch,) + tuple(x.shape[1:])
     elif m == 1:
@@ -291,14 +303,14 @@ def detect(x, mode="intensity", nscrunch=1):
     else:
         oshape = (n // nscrunch, nchan, 4)
     if isinstance(x, DeviceArray):
-        out = DeviceArray.empty(oshape, np.float32, device=x.device_index)
+        out = DeviceArray.empty(oshape, rdt, device=x.device_index)
         dev, stream = x.device_index, _stream_ptr(x.device_index)
     else:
-        out = np.empty(oshape, dtype=np.float32)
+        out = np.empty(oshape, dtype=rdt)
         dev, stream = 0, C.c_void_p(0)
     pin, lin = _ptr_loc(x)
     pout, lout = _ptr_loc(out)
-    _check(lib().pbh_detect(dev, stream, pin, pout, int(n), int(nchan), npol, m, int(nscrunch), lin, lout))
+    _check(lib().pbh_detect(dev, stream, code, pin, pout, int(n), int(nchan), npol, m, int(nscrunch), lin, lout))
     return out
 
 
@@ -306,20 +318,19 @@ def fft_c2c(x, inverse=False):
     """c2c FFT along axis 0 of an (n, ...) c64 array (numpy or DeviceArray), scipy norm=None."""
     from .device import DeviceArray
     _require_device()
-    if x.dtype != np.complex64:
-        raise TypeError("fft_c2c needs complex64 data")
+    code = _dtype_code(x.dtype)
     n = x.shape[0]
     batch = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
     if isinstance(x, DeviceArray):
-        out = DeviceArray.empty(x.shape, np.complex64, device=x.device_index)
+        out = DeviceArray.empty(x.shape, x.dtype, device=x.device_index)
         dev, stream = x.device_index, _stream_ptr(x.device_index)
     else:
         x = np.ascontiguousarray(x)
-        out = np.empty(x.shape, dtype=np.complex64)
+        out = np.empty(x.shape, dtype=x.dtype)
         dev, stream = 0, C.c_void_p(0)
     pin, lin = _ptr_loc(x)
     pout, lout = _ptr_loc(out)
-    _check(lib().pbh_fft_c2c(dev, stream, pin, pout, int(n), batch, int(bool(inverse)), lin, lout))
+    _check(lib().pbh_fft_c2c(dev, stream, code, pin, pout, int(n), batch, int(bool(inverse)), lin, lout))
     return out
 
 

@@ -2,7 +2,7 @@
 #pragma once
 #include "fft_core.hpp"
 
-namespace pbh {
+namespace PBH_NS {
 
 // ---- K1: chirp (transfer function) ----------------------------------------------------------------
 // Reproduces _transfer_function (pulsarbat/transforms/dedispersion.py:19-23) in float64:
@@ -19,7 +19,7 @@ struct ChirpParams {
     double coeff, inv_ndt, inv_ref;
     int64_t N;
     int N1, N2, nchan;
-    float scale;
+    real scale;
     int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
 };
 
@@ -44,13 +44,16 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
         const double fr = phi - rint(phi);
         double sn, cs;
         sincospi(2.0 * fr, &sn, &cs);
-        p.out[d] = make_float2((float)cs * p.scale, (float)(-sn) * p.scale);
+        // the reference rounds the transfer function to complex64 (dedispersion.py:23) for both data dtypes
+        p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
     }
 }
 
-// natural (N, nchan) <-> plan order [chan][k1][k2]; `to_plan` selects the direction.
-__global__ __launch_bounds__(256) void k_chirp_reorder(const cf* __restrict__ src, cf* __restrict__ dst,
-                                                       int64_t N, int N1, int N2, int nchan, float scale,
+// natural (N, nchan) complex64 (the reference's chirp dtype) <-> plan order [chan][k1][k2] in the
+// plan's precision; `to_plan` selects the direction.
+__global__ __launch_bounds__(256) void k_chirp_reorder(const float2* __restrict__ nat_in, float2* __restrict__ nat_out,
+                                                       const cf* __restrict__ plan_in, cf* __restrict__ plan_out,
+                                                       int64_t N, int N1, int N2, int nchan, real scale,
                                                        int to_plan, int perm_w) {
     const int64_t total = N * nchan;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
@@ -61,11 +64,11 @@ __global__ __launch_bounds__(256) void k_chirp_reorder(const cf* __restrict__ sr
         const int64_t k = k1 + (int64_t)N1 * k2;
         const int64_t nat = k * nchan + chan;
         if (to_plan) {
-            cf a = src[nat];
-            dst[d] = make_float2(a.x * scale, a.y * scale);
+            const float2 v = nat_in[nat];
+            plan_out[d] = make_cf((real)v.x * scale, (real)v.y * scale);
         } else {
-            cf a = src[d];
-            dst[nat] = make_float2(a.x * scale, a.y * scale);
+            const cf v = plan_in[d];
+            nat_out[nat] = make_float2((float)(v.x * scale), (float)(v.y * scale));
         }
     }
 }
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
     }
 }
 
+#ifndef PBH_F64
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the
 // streaming-copy calibration (tools/micro/membench.hip) found fastest on MI355X.
@@ -131,11 +135,11 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
         const int e = 2 * (threadIdx.x + 256 * j);
         const int n = e / S, s = e % S;
         if (S == 1) {  // two consecutive times of the single series
-            lds[e] = make_float2(v[j].x, v[j].y);
-            lds[e + 1] = make_float2(v[j].z, v[j].w);
+            lds[e] = make_cf(v[j].x, v[j].y);
+            lds[e + 1] = make_cf(v[j].z, v[j].w);
         } else {
-            lds[s * LD + n] = make_float2(v[j].x, v[j].y);
-            lds[(s + 1) * LD + n] = make_float2(v[j].z, v[j].w);
+            lds[s * LD + n] = make_cf(v[j].x, v[j].y);
+            lds[(s + 1) * LD + n] = make_cf(v[j].z, v[j].w);
         }
     }
     __syncthreads();
@@ -189,9 +193,11 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
     }
 }
 
+#endif  // !PBH_F64
+
 // ---- detection (pulsarbat/core.py:766-774, 930-966), optional time scrunch -----------------------------
 // in: (n, nchan, npol) c64.  One thread per (output row, chan); sums nscrunch input rows in float32.
-__global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, real* __restrict__ out,
                                                 int64_t nout, int nchan, int npol, int mode, int nscrunch) {
     const int64_t total = nout * nchan;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float
         const int chan = (int)(d - o * nchan);
         if (mode == 0) {
             for (int pp = 0; pp < npol; ++pp) {
-                float acc = 0.f;
+                real acc = 0;
                 for (int j = 0; j < nscrunch; ++j) {
                     cf a = in[((o * nscrunch + j) * nchan + chan) * npol + pp];
                     acc += a.x * a.x + a.y * a.y;
@@ -208,24 +214,24 @@ __global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float
                 out[d * npol + pp] = acc;
             }
         } else {
-            float si = 0.f, sq = 0.f, su = 0.f, sv = 0.f;
+            real si = 0, sq = 0, su = 0, sv = 0;
             for (int j = 0; j < nscrunch; ++j) {
                 const cf* base = in + ((o * nscrunch + j) * nchan + chan) * 2;
                 cf a = base[0], b = base[1];
-                float aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
-                float re = a.x * b.x + a.y * b.y;  // Re(conj(a) b)
-                float im = a.x * b.y - a.y * b.x;  // Im(conj(a) b)
+                real aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
+                real re = a.x * b.x + a.y * b.y;  // Re(conj(a) b)
+                real im = a.x * b.y - a.y * b.x;  // Im(conj(a) b)
                 si += aa + bb;
                 if (mode == 2) {
-                    sq += aa - bb; su += 2.f * re; sv += 2.f * im;
+                    sq += aa - bb; su += 2 * re; sv += 2 * im;
                 } else if (mode == 3) {
-                    sq += 2.f * re; su += 2.f * im; sv += aa - bb;
+                    sq += 2 * re; su += 2 * im; sv += aa - bb;
                 }
             }
             if (mode == 1) {
                 out[d] = si;
             } else {
-                float* o4 = out + d * 4;
+                real* o4 = out + d * 4;
                 o4[0] = si; o4[1] = sq; o4[2] = su; o4[3] = sv;
             }
         }
@@ -238,13 +244,13 @@ __global__ __launch_bounds__(256) void k_detect(const cf* __restrict__ in, float
 // bin of one channel: lanes stride over the bin's nscrunch consecutive samples (coalesced 512-B reads
 // per polarisation), accumulate in float32 and finish with a 64-lane butterfly reduction.
 //   mode 0: |z|^2 per pol -> out[o][chan][pol];  1: Stokes I -> out[o][chan];  2/3: IQUV -> out[o][chan][4]
-__device__ __forceinline__ float wave_sum(float x) {
+__device__ __forceinline__ real wave_sum(real x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
 }
 
-__global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ work, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ work, real* __restrict__ out,
                                                        int64_t plane, int64_t start, int64_t nout, int nchan,
                                                        int npol, int mode, int nscrunch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
     if (mode == 0) {
         for (int pp = 0; pp < npol; ++pp) {
             const cf* a = work + (int64_t)(chan * npol + pp) * plane + t0;
-            float acc = 0.f;
+            real acc = 0;
             for (int i = lane; i < nscrunch; i += 64) acc += a[i].x * a[i].x + a[i].y * a[i].y;
             acc = wave_sum(acc);
             if (lane == 0) out[(o * nchan + chan) * npol + pp] = acc;
@@ -264,15 +270,15 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
     }
     const cf* pa = work + (int64_t)(chan * 2) * plane + t0;
     const cf* pb = pa + plane;
-    float si = 0.f, sq = 0.f, su = 0.f, sv = 0.f;
+    real si = 0, sq = 0, su = 0, sv = 0;
     for (int i = lane; i < nscrunch; i += 64) {
         const cf a = pa[i], b = pb[i];
-        const float aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
+        const real aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
         si += aa + bb;
         if (mode >= 2) {
-            const float re = a.x * b.x + a.y * b.y, im = a.x * b.y - a.y * b.x;  // conj(a) * b
-            if (mode == 2) { sq += aa - bb; su += 2.f * re; sv += 2.f * im; }
-            else { sq += 2.f * re; su += 2.f * im; sv += aa - bb; }
+            const real re = a.x * b.x + a.y * b.y, im = a.x * b.y - a.y * b.x;  // conj(a) * b
+            if (mode == 2) { sq += aa - bb; su += 2 * re; sv += 2 * im; }
+            else { sq += 2 * re; su += 2 * im; sv += aa - bb; }
         }
     }
     si = wave_sum(si);
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
     }
     sq = wave_sum(sq); su = wave_sum(su); sv = wave_sum(sv);
     if (lane == 0) {
-        float* o4 = out + (o * nchan + chan) * 4;
+        real* o4 = out + (o * nchan + chan) * 4;
         o4[0] = si; o4[1] = sq; o4[2] = su; o4[3] = sv;
     }
 }
@@ -301,7 +307,7 @@ __device__ __forceinline__ cf bs_chirp(int64_t n, int64_t N, double sign) {
     const int64_t r = (n * n) % (2 * N);
     double s, c;
     sincospi((double)r / (double)N, &s, &c);
-    return make_float2((float)c, (float)(sign * s));
+    return make_cf((real)c, (real)(sign * s));
 }
 
 // b[n] = exp(-i pi n^2/N), n < N
@@ -311,12 +317,12 @@ __global__ __launch_bounds__(256) void k_bs_table(cf* __restrict__ b, int64_t N)
 }
 
 // wrapped convolution kernel conj(b)[m] for |m| < N on a ring of L points, times `scale`
-__global__ __launch_bounds__(256) void k_bs_kernel(cf* __restrict__ c, int64_t N, int64_t L, float scale) {
+__global__ __launch_bounds__(256) void k_bs_kernel(cf* __restrict__ c, int64_t N, int64_t L, real scale) {
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < L; m += (int64_t)gridDim.x * blockDim.x) {
-        cf v = make_float2(0.f, 0.f);
+        cf v = make_cf(0, 0);
         if (m < N) v = bs_chirp(m, N, +1.0);
         else if (m > L - N) v = bs_chirp(L - m, N, +1.0);
-        c[m] = make_float2(v.x * scale, v.y * scale);
+        c[m] = make_cf(v.x * scale, v.y * scale);
     }
 }
 
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void k_bs_pre(const cf* __restrict__ x, const 
     const int64_t total = L * S;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = e / S;
-        cf v = make_float2(0.f, 0.f);
+        cf v = make_cf(0, 0);
         if (n < N) v = cmul(x[e], b[n]);
         a[e] = v;
     }
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void k_bs_mid(const cf* __restrict__ conv, con
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t k = e / S;
         const int s = (int)(e - k * S);
-        cf v = make_float2(0.f, 0.f);
+        cf v = make_cf(0, 0);
         if (k < N) v = cconj(cmul(conv[e], H[(int64_t)(s / npol) * N + k]));
         a[e] = v;
     }
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(256) void k_bs_post(const cf* __restrict__ conv, co
     }
 }
 
+#ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -362,4 +369,6 @@ __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, flo
         out[i] = in[i];
 }
 
-}  // namespace pbh
+#endif  // !PBH_F64
+
+}  // namespace PBH_NS

@@ -17,25 +17,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace pbh {
+#include "pbh_config.hpp"
 
-typedef float2 cf;
+namespace PBH_NS {
 
-constexpr int kTileLog2 = 14;
+typedef PBH_REAL real;
+typedef PBH_REAL2 cf;
+__host__ __device__ __forceinline__ cf make_cf(real x, real y) { return PBH_MAKE2(x, y); }
+
+constexpr int kTileLog2 = PBH_TILE_LOG2;
 constexpr int kTilePoints = 1 << kTileLog2;  // complex points per workgroup tile
 constexpr int kTwTable = 1 << 14;            // stage twiddle table: W_16384^p (forward sign)
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_cf(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_cf(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_cf(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ cf csqr(cf a) { return make_float2(a.x * a.x - a.y * a.y, 2.0f * a.x * a.y); }
-__device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ cf csqr(cf a) { return make_cf(a.x * a.x - a.y * a.y, RC(2.0) * a.x * a.y); }
+__device__ __forceinline__ cf cconj(cf a) { return make_cf(a.x, -a.y); }
 // multiply by -i (DIR = -1, forward) or +i (DIR = +1, inverse)
 template <int DIR>
 __device__ __forceinline__ cf mul_i(cf a) {
-    return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+    return DIR < 0 ? make_cf(a.y, -a.x) : make_cf(-a.y, a.x);
 }
 
 // Multiply by W_32^p (forward: exp(-2 pi i p/32); inverse: conjugate).  p is a compile-time
@@ -45,20 +49,20 @@ __device__ __forceinline__ cf mul_w32(cf a, int p) {
     p &= 31;
     const int quad = p >> 3, r = p & 7;
     if (r != 0) {
-        float c, s;
+        real c, s;
         switch (r) {
-            case 1: c = 0.98078528040323043f; s = 0.19509032201612825f; break;
-            case 2: c = 0.92387953251128674f; s = 0.38268343236508977f; break;
-            case 3: c = 0.83146961230254524f; s = 0.55557023301960218f; break;
-            case 4: c = 0.70710678118654752f; s = 0.70710678118654752f; break;
-            case 5: c = 0.55557023301960218f; s = 0.83146961230254524f; break;
-            case 6: c = 0.38268343236508977f; s = 0.92387953251128674f; break;
-            default: c = 0.19509032201612825f; s = 0.98078528040323043f; break;
+            case 1: c = RC(0.98078528040323043); s = RC(0.19509032201612825); break;
+            case 2: c = RC(0.92387953251128674); s = RC(0.38268343236508977); break;
+            case 3: c = RC(0.83146961230254524); s = RC(0.55557023301960218); break;
+            case 4: c = RC(0.70710678118654752); s = RC(0.70710678118654752); break;
+            case 5: c = RC(0.55557023301960218); s = RC(0.83146961230254524); break;
+            case 6: c = RC(0.38268343236508977); s = RC(0.92387953251128674); break;
+            default: c = RC(0.19509032201612825); s = RC(0.98078528040323043); break;
         }
-        a = cmul(a, make_float2(c, DIR < 0 ? -s : s));
+        a = cmul(a, make_cf(c, DIR < 0 ? -s : s));
     }
     if (quad == 1) return mul_i<DIR>(a);
-    if (quad == 2) return make_float2(-a.x, -a.y);
+    if (quad == 2) return make_cf(-a.x, -a.y);
     if (quad == 3) return mul_i<-DIR>(a);
     return a;
 }
@@ -160,7 +164,7 @@ constexpr int lds_lin(int d) {
 }
 template <bool PAD>
 constexpr int lds_tile_bytes() {
-    return (PAD ? kTilePoints + (kTilePoints >> 5) : kTilePoints) * (int)sizeof(float2);
+    return (PAD ? kTilePoints + (kTilePoints >> 5) : kTilePoints) * (int)sizeof(cf);
 }
 
 // Load the per-stage twiddle seeds W_{NS*RAD}^{k} for this thread (global table, L2-resident).
@@ -291,19 +295,19 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
         }
         if constexpr (!LAST && XS) {
             static_assert(!PAD, "split exchange is implemented for unpadded (column) tiles");
-            float* fl = reinterpret_cast<float*>(lds);
+            real* fl = reinterpret_cast<real*>(lds);
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
 #pragma unroll
                 for (int q = 0; q < NB; ++q) {
                     const int jb = tau + q * MR;
                     const int k = jb & (NS - 1);
-                    float* wp = fl + ((jb - k) * RAD + k) * PS + fofs;
+                    real* wp = fl + ((jb - k) * RAD + k) * PS + fofs;
 #pragma unroll
                     for (int u = 0; u < RAD; ++u) wp[u * NS * PS] = part ? v[q + u * NB].y : v[q + u * NB].x;
                 }
                 __syncthreads();
-                const float* rp = fl + tau * PS + fofs;
+                const real* rp = fl + tau * PS + fofs;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     if (part) v[i].y = rp[i * MR * PS];
@@ -332,12 +336,25 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
 // ---- buffer (SRD) addressing: wave-uniform base in SGPRs, 32-bit per-lane offset, scalar step ----
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+#ifdef PBH_F64
+__device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
+    union { u32x4 u; cf c; } x;
+    x.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return x.c;
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
+    union { u32x4 u; cf c; } x;
+    x.c = a;
+    __builtin_amdgcn_raw_buffer_store_b128(x.u, r, voff, soff, 0);
+}
+#else
 __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
     u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+    return make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
 }
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     u32x2 x;
@@ -345,6 +362,7 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     x.y = __float_as_uint(a.y);
     __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
+#endif
 
 // ---- float64 inter-pass twiddles W_N^p via a two-level table ------------------------------------
 struct BigTwiddle {
@@ -363,4 +381,4 @@ __device__ __forceinline__ double2 big_tw(const BigTwiddle& t, int64_t p) {
     return zmul(a, b);
 }
 
-}  // namespace pbh
+}  // namespace PBH_NS

@@ -15,7 +15,7 @@
 #pragma once
 #include "fft_core.hpp"
 
-namespace pbh {
+namespace PBH_NS {
 
 enum ColOp { OP_FWD_TW = 0, OP_TW_INV = 1 };
 enum Layout { LAYOUT_INTERLEAVED = 0, LAYOUT_PLANAR = 1, LAYOUT_BLOCK = 2 };
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p
         const cf* src = p.in + col_addr(p.is, tau, n2, s, p.S, p.N2);
         const int64_t step = (int64_t)MR * p.is.row_stride;
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = valid ? src[i * step] : make_float2(0.f, 0.f);
+        for (int i = 0; i < R; ++i) v[i] = valid ? src[i * step] : make_cf(0, 0);
     }
     cf* dst = p.out + col_addr(p.os, tau, n2, s, p.S, p.N2) - p.out_shift;
     const int64_t ostep = (int64_t)MR * p.os.row_stride;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p
         double2 z = zb;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            v[i] = cmul(v[i], make_float2((float)z.x, (float)-z.y));
+            v[i] = cmul(v[i], make_cf((real)z.x, (real)-z.y));
             z = zmul(z, zs);
         }
         fft_tile<M, 1, R, +1, F, PAD, XS>(v, lds, tau, f, w);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p
         double2 z = zb;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            cf r = cmul(v[i], make_float2((float)z.x, (float)z.y));
+            cf r = cmul(v[i], make_cf((real)z.x, (real)z.y));
             z = zmul(z, zs);
             if (valid) dst[i * ostep] = r;
         }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
             cf c[R];
 #pragma unroll
             for (int i = 0; i < R; ++i)
-                c[i] = (ABL == 2 || ABL == 3) ? make_float2(0.999f, 0.001f * i) : buf_load(rc, voff, i * STEP);
+                c[i] = (ABL == 2 || ABL == 3) ? make_cf(RC(0.999), RC(0.001) * i) : buf_load(rc, voff, i * STEP);
             if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
             for (int i = 0; i < R; ++i) v[i] = cmul(v[i], c[i]);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
             }
             if (!more) break;
 #pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = (ABL == 3) ? make_float2(v[i].x + nx[i].y, v[i].y) : nx[i];
+            for (int i = 0; i < R; ++i) v[i] = (ABL == 3) ? make_cf(v[i].x + nx[i].y, v[i].y) : nx[i];
         } else {
             fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowfft(cf* data, const cf* 
     for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
 }
 
+#ifndef PBH_F64
 // ---- fused row pass, wave-decoupled form (M = 16384 = 8 x 2048) ------------------------------------------
 // k = ka + 8 kb, n = 2048 na + nb.  Forward: radix-8 over na inside each thread (its 32 points
 // tau + 512 i contain na = 0..7 for four values of nb), twiddle W_M^{nb ka}, ONE cross-wave exchange
@@ -416,6 +417,8 @@ __global__ __launch_bounds__(512) void k_row2(RowParams p) {
     }
 }
 
+#endif  // !PBH_F64
+
 // ---- single-tile transform (nsample = M <= 2^14) -------------------------------------------------------
 struct SmallParams {
     const cf* in;     // (M, S) interleaved
@@ -425,7 +428,7 @@ struct SmallParams {
     int S, npol;
     int64_t crop_start, crop_stop;
     int dir;      // plain-FFT mode only: -1 forward, +1 inverse
-    float scale;  // plain-FFT mode only
+    real scale;   // plain-FFT mode only
 };
 
 template <int M, int R>
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     } else {
         fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = make_float2(v[i].x * p.scale, v[i].y * p.scale);
+        for (int i = 0; i < R; ++i) v[i] = make_cf(v[i].x * p.scale, v[i].y * p.scale);
     }
     // output rows [crop_start, crop_stop) -> out row (row - crop_start)
     const int64_t nout_rows = p.crop_stop - p.crop_start;
@@ -482,4 +485,4 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     }
 }
 
-}  // namespace pbh
+}  // namespace PBH_NS

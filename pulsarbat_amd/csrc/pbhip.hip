@@ -1,4 +1,28 @@
 // pbhip.hip -- host side of libpbhip.so: plans, launch sequences and the C ABI of include/pbhip.h.
+// Compiled twice (float32, and float64 with -DPBH_F64): every public name below is renamed to the
+// per-precision prefix (pbh32_* / pbh64_*); pbhip_api.cpp owns the public pbh_* symbols and dispatches
+// on the plan's dtype.
+#include "pbh_config.hpp"
+#define pbh_plan PBH_FN(plan)
+#define pbh_device_count PBH_FN(device_count)
+#define pbh_last_error PBH_FN(last_error)
+#define pbh_version PBH_FN(version)
+#define pbh_plan_create PBH_FN(plan_create)
+#define pbh_plan_destroy PBH_FN(plan_destroy)
+#define pbh_plan_set_stream PBH_FN(plan_set_stream)
+#define pbh_plan_set_variant PBH_FN(plan_set_variant)
+#define pbh_plan_info PBH_FN(plan_info)
+#define pbh_chirp_generate PBH_FN(chirp_generate)
+#define pbh_chirp_upload PBH_FN(chirp_upload)
+#define pbh_chirp_download PBH_FN(chirp_download)
+#define pbh_chirp_function PBH_FN(chirp_function)
+#define pbh_dedisperse PBH_FN(dedisperse)
+#define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
+#define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
+#define pbh_detect PBH_FN(detect)
+#define pbh_fft_c2c PBH_FN(fft_c2c)
+#define pbh_plan_profile PBH_FN(plan_profile)
+#define pbh_copy_bench PBH_FN(copy_bench)
 #include "../../include/pbhip.h"
 
 #include <hip/hip_runtime.h>
@@ -14,7 +38,7 @@
 #include "aux_kernels.hpp"
 #include "kernels.hpp"
 
-using namespace pbh;
+using namespace PBH_NS;
 
 // ---- error plumbing ------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -119,7 +143,13 @@ static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads
     return PBH_OK;
 }
 
+#ifdef PBH_F64
+#define FOR_ALL_M(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
+#define FOR_ROW_M(X) X(1024) X(2048) X(4096) X(8192)
+#else
 #define FOR_ALL_M(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
+#define FOR_ROW_M(X) X(1024) X(2048) X(4096) X(8192) X(16384)
+#endif
 
 static int row_grid() {
     static int g = [] {
@@ -146,7 +176,7 @@ static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
     // (cache-policy experiments on the partial-line variants: non-temporal loads/stores 2-3x slower --
     //  they defeat the L2 merging --, sc1 loads -5 % at best)
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_col<m, OP, 32, false>, prm, ntile, kTilePoints / 32, st);
+#define X(m) case m: return launch_tile_kernel(k_col<m, OP, PBH_R, false>, prm, ntile, kTilePoints / PBH_R, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -157,18 +187,18 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (prm.nrows + FR - 1) / FR;
     if (tiles > row_grid()) tiles = row_grid();
-#ifdef PBH_DIAGNOSTIC  // ablation builds: -DPBH_DIAGNOSTIC, then PBH_ROW_ABL=1|2|3
+#if defined(PBH_DIAGNOSTIC) && !defined(PBH_F64)  // ablation builds: -DPBH_DIAGNOSTIC, then PBH_ROW_ABL=1|2|3
     static int abl = [] { const char* e = getenv("PBH_ROW_ABL"); return e ? atoi(e) : 0; }();
     if (M == 16384 && abl == 1) return launch_tile_kernel(k_row<16384, 32, true, 1>, prm, tiles, 512, st);
     if (M == 16384 && abl == 2) return launch_tile_kernel(k_row<16384, 32, true, 2>, prm, tiles, 512, st);
     if (M == 16384 && abl == 3) return launch_tile_kernel(k_row<16384, 32, true, 3>, prm, tiles, 512, st);
 #endif
-    if (prm.perm_w == 8) {
-        return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
-    }
+#ifndef PBH_F64
+    if (prm.perm_w == 8) return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
+#endif
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_row<m, 32, true>, prm, tiles, kTilePoints / 32, st);
-        X(1024) X(2048) X(4096) X(8192) X(16384)
+#define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st);
+        FOR_ROW_M(X)
 #undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
@@ -180,7 +210,7 @@ static int launch_small(int M, const SmallParams& prm, hipStream_t st) {
         return fail(PBH_ERR_UNSUPPORTED, "single-tile block larger than 2 GiB (too many series)");
     const int64_t tiles = ((int64_t)prm.S + F - 1) / F;
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_small<m, 32>, prm, tiles, kTilePoints / 32, st);
+#define X(m) case m: return launch_tile_kernel(k_small<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st);
         FOR_ALL_M(X)
 #undef X
     }
@@ -194,6 +224,7 @@ static int tr_rows(int S) {
 
 static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
     const int TN = tr_rows(S);
+#ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 32 && N % TN == 0) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
@@ -201,10 +232,12 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStre
             X(1) X(2) X(4) X(8) X(16) X(32)
 #undef X
         }
-    } else {
-        hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
-                           (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N);
+        HIPCHECK(hipGetLastError());
+        return PBH_OK;
     }
+#endif
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
+                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -214,6 +247,7 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     if (stop <= start) return PBH_OK;
     const int TN = tr_rows(S);
     int64_t done = 0;
+#ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 32) {
         const int64_t full = (stop - start) / TN;
         if (full > 0) {
@@ -226,6 +260,7 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
         }
         done = full * TN;
     }
+#endif
     if (start + done < stop) {  // tail (or everything, for other S) through the generic kernel
         const int64_t s2 = start + done;
         hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - s2 + TN - 1) / TN)), dim3(256),
@@ -237,7 +272,7 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
 
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
 struct DetectTail {
-    float* out = nullptr;  // non-null: replace the final layout pass by detect + scrunch into `out`
+    real* out = nullptr;   // non-null: replace the final layout pass by detect + scrunch into `out`
     int mode = 0, nscrunch = 1;
 };
 
@@ -275,7 +310,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         return steps;
     }
     if (p->N1 == 1) {
-        SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, 1.0f};
+        SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, (real)1};
         const int M = (int)p->N;
         steps.push_back({"k_small", [=](hipStream_t st) { return launch_small(M, sp, st); }});
         return steps;
@@ -359,14 +394,14 @@ static int launch_rowfft(int M, cf* data, const cf* tw, int64_t nrows, hipStream
     switch (M) {
 #define X(m)                                                                                               \
     case m: {                                                                                              \
-        auto kern = k_rowfft<m, 32>;                                                                       \
+        auto kern = k_rowfft<m, PBH_R>;                                                                    \
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                      lds_tile_bytes<true>()));                                             \
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kTilePoints / 32), lds_tile_bytes<true>(), st, \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kTilePoints / PBH_R), lds_tile_bytes<true>(), st, \
                            data, tw, nrows);                                                               \
         break;                                                                                             \
     }
-        X(1024) X(2048) X(4096) X(8192) X(16384)
+        FOR_ROW_M(X)
 #undef X
         default: return fail(PBH_ERR_UNSUPPORTED, "row FFT length " + std::to_string(M));
     }
@@ -382,7 +417,11 @@ extern "C" int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int 
 // row pass leave bin k1 + N1 k2 at position k1*N2 + k2, which is the chirp layout).
 static int setup_bluestein(pbh_plan* p) {
     const int64_t N = p->N, L = p->bsL;
+    #ifdef PBH_F64
+    PBHCHECK(pbh_plan_create(&p->sub, p->device, L, 1, p->S, PBH_C128, 0, L));
+#else
     PBHCHECK(pbh_plan_create(&p->sub, p->device, L, 1, p->S, PBH_C64, 0, L));
+#endif
     pbh_plan* q = p->sub;
     q->perm_w = 0;  // its "chirp" is produced below by a forward FFT, i.e. in natural plan order
     p->owned_bytes += q->owned_bytes;
@@ -392,12 +431,12 @@ static int setup_bluestein(pbh_plan* p) {
     hipStream_t st = nullptr;
     hipLaunchKernelGGL(k_bs_table, dim3(1024), dim3(256), 0, st, p->bs_b, N);
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_bs_kernel, dim3(2048), dim3(256), 0, st, q->chirp, N, L, (float)(1.0 / (double)L));
+    hipLaunchKernelGGL(k_bs_kernel, dim3(2048), dim3(256), 0, st, q->chirp, N, L, (real)(1.0 / (double)L));
     HIPCHECK(hipGetLastError());
     if (q->N1 == 1) {
         // single tile: forward FFT of one series, out of place through the (still unused) bs_a buffer
         HIPCHECK(hipMemcpyAsync(p->bs_a, q->chirp, sizeof(cf) * (size_t)L, hipMemcpyDeviceToDevice, st));
-        SmallParams sp{p->bs_a, q->chirp, nullptr, q->tw16k, 1, 1, 0, L, -1, 1.0f};
+        SmallParams sp{p->bs_a, q->chirp, nullptr, q->tw16k, 1, 1, 0, L, -1, (real)1};
         PBHCHECK(launch_small((int)L, sp, st));
     } else {
         BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
@@ -417,7 +456,10 @@ extern "C" {
 
 int pbh_device_count(void) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
     return n;
 }
 
@@ -430,8 +472,12 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
     if (!out) return fail(PBH_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
-    if (dtype != PBH_C64) return fail(PBH_ERR_UNSUPPORTED, "only complex64 is implemented");
-    const bool pow2 = is_pow2(nsample) && nsample >= 32;
+#ifdef PBH_F64
+    if (dtype != PBH_C128) return fail(PBH_ERR_INVALID, "dtype mismatch (float64 build)");
+#else
+    if (dtype != PBH_C64) return fail(PBH_ERR_INVALID, "dtype mismatch (float32 build)");
+#endif
+    const bool pow2 = is_pow2(nsample) && nsample >= PBH_R;
     if (nsample < 2 || nsample > (1LL << 28) || (!pow2 && nsample > (1LL << 27)))
         return fail(PBH_ERR_UNSUPPORTED, "nsample must be in [2, 2^28] (powers of two) or [2, 2^27] (other lengths); got " +
                                              std::to_string(nsample));
@@ -455,21 +501,26 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
     if (!pow2) {
         p->N1 = 1;  // natural-order chirp H/N; the transforms run in the power-of-two sub-plan
         p->N2 = (int)nsample;
-        int64_t L = 32;
+        int64_t L = PBH_R;
         while (L < 2 * nsample - 1) L <<= 1;
         p->bsL = L;
     } else if (n <= kTileLog2) {
         p->N1 = 1;
         p->N2 = (int)nsample;
     } else {
-        const int l2 = (n - 5 < kTileLog2) ? n - 5 : kTileLog2;
+        const int l2 = (n - PBH_LOG2R < kTileLog2) ? n - PBH_LOG2R : kTileLog2;
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
     }
     {
         const char* e = getenv("PBH_ROW2");
         const bool want = e ? atoi(e) != 0 : false;
+#ifdef PBH_F64
+        p->perm_w = 0;
+        (void)want;
+#else
         p->perm_w = (want && p->N1 > 1 && p->N2 == 16384) ? 8 : 0;
+#endif
     }
     int rc = PBH_OK;
     auto bail = [&](int code) {
@@ -481,7 +532,7 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
         std::vector<cf> h(kTwTable);
         for (int i = 0; i < kTwTable; ++i) {
             double a = -2.0 * M_PI * (double)i / (double)kTwTable;
-            h[i] = make_float2((float)cos(a), (float)sin(a));
+            h[i] = make_cf((real)cos(a), (real)sin(a));
         }
         if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable)) != PBH_OK) return bail(rc);
         if (hipMemcpy(p->tw16k, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
@@ -571,7 +622,7 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
 }
 
 // ---- chirp --------------------------------------------------------------------------------------------------
-static float inv_n(const pbh_plan* p) { return (float)(1.0 / (double)p->N); }
+static real inv_n(const pbh_plan* p) { return (real)(1.0 / (double)p->N); }
 
 int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* chan_freq_hz, double ref_freq_hz) {
     if (!p || !chan_freq_hz) return fail(PBH_ERR_INVALID, "NULL argument");
@@ -590,15 +641,15 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
 int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
     if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     HIPCHECK(hipSetDevice(p->device));
-    const size_t bytes = sizeof(cf) * (size_t)p->nchan * p->N;
-    const cf* src = (const cf*)chirp_c64;
+    const size_t bytes = sizeof(float2) * (size_t)p->nchan * p->N;  // the external chirp is complex64
+    const float2* src = (const float2*)chirp_c64;
     if (loc == PBH_HOST) {
         PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, bytes));
         HIPCHECK(hipMemcpyAsync(p->stage_in, chirp_c64, bytes, hipMemcpyHostToDevice, p->stream));
-        src = (const cf*)p->stage_in;
+        src = (const float2*)p->stage_in;
     }
-    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, p->chirp, p->N, p->N1, p->N2,
-                       p->nchan, inv_n(p), 1, p->perm_w);
+    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, (float2*)nullptr,
+                       (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
@@ -609,14 +660,14 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
     if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     if (!p->has_chirp) return fail(PBH_ERR_STATE, "plan has no chirp yet");
     HIPCHECK(hipSetDevice(p->device));
-    const size_t bytes = sizeof(cf) * (size_t)p->nchan * p->N;
-    cf* dst = (cf*)chirp_c64;
+    const size_t bytes = sizeof(float2) * (size_t)p->nchan * p->N;
+    float2* dst = (float2*)chirp_c64;
     if (loc == PBH_HOST) {
         PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, bytes));
-        dst = (cf*)p->stage_out;
+        dst = (float2*)p->stage_out;
     }
-    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const cf*)p->chirp, dst, p->N, p->N1,
-                       p->N2, p->nchan, (float)p->N, 0, p->perm_w);
+    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const float2*)nullptr, dst,
+                       (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
         HIPCHECK(hipMemcpyAsync(chirp_c64, dst, bytes, hipMemcpyDeviceToHost, p->stream));
@@ -625,6 +676,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
     return PBH_OK;
 }
 
+#ifndef PBH_F64
 int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t nsample, double dt_s,
                        double center_freq_hz, double ref_freq_hz, void* chirp_c64, int loc) {
     if (!chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
@@ -658,6 +710,8 @@ int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t ns
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_chirp_function: ") + hipGetErrorString(e));
     return PBH_OK;
 }
+
+#endif  // !PBH_F64
 
 // ---- hot path --------------------------------------------------------------------------------------------------
 static int resolve_io(pbh_plan* p, const void* in, void* out, size_t out_bytes, int in_loc, int out_loc,
@@ -705,7 +759,7 @@ static int detect_out_elems(int mode, int npol) {
     return 0;
 }
 
-static int launch_detect(hipStream_t st, const cf* in, float* out, int64_t nout, int nchan, int npol, int mode,
+static int launch_detect(hipStream_t st, const cf* in, real* out, int64_t nout, int nchan, int npol, int mode,
                          int nscrunch) {
     if (nout <= 0) return PBH_OK;
     int64_t blocks = (nout * nchan + 255) / 256;
@@ -715,8 +769,8 @@ static int launch_detect(hipStream_t st, const cf* in, float* out, int64_t nout,
     return PBH_OK;
 }
 
-int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, int64_t nsample, int nchan,
-               int npol, int mode, int nscrunch, int in_loc, int out_loc) {
+int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_c64, void* out_f32,
+               int64_t nsample, int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc) {
     if (!in_c64 || !out_f32) return fail(PBH_ERR_INVALID, "NULL argument");
     if (nsample <= 0 || nchan <= 0 || npol <= 0 || nscrunch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
     const int oe = detect_out_elems(mode, npol);
@@ -726,9 +780,9 @@ int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, 
     hipStream_t st = (hipStream_t)hip_stream;
     const int64_t nout = nsample / nscrunch;
     const size_t in_bytes = sizeof(cf) * (size_t)nsample * nchan * npol;
-    const size_t out_bytes = sizeof(float) * (size_t)nout * nchan * oe;
+    const size_t out_bytes = sizeof(real) * (size_t)nout * nchan * oe;
     const cf* din = (const cf*)in_c64;
-    float* dout = (float*)out_f32;
+    real* dout = (real*)out_f32;
     void *sin = nullptr, *sout = nullptr;
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
@@ -741,7 +795,7 @@ int pbh_detect(int device, void* hip_stream, const void* in_c64, void* out_f32, 
             if (sin) hipFree(sin);
             return rc;
         }
-        dout = (float*)sout;
+        dout = (real*)sout;
     }
     rc = launch_detect(st, din, dout, nout, nchan, npol, mode, nscrunch);
     hipError_t e = hipSuccess;
@@ -769,14 +823,14 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     HIPCHECK(hipSetDevice(p->device));
     const int64_t nvalid = p->stop - p->start;
     const int64_t nout = nvalid / nscrunch;
-    const size_t out_bytes = sizeof(float) * (size_t)nout * p->nchan * oe;
+    const size_t out_bytes = sizeof(real) * (size_t)nout * p->nchan * oe;
     const size_t mid_bytes = sizeof(cf) * (size_t)p->S * (size_t)nvalid;
     const cf* din;
     void* dout;
     PBHCHECK(resolve_io(p, in_c64, out_f32, out_bytes, in_loc, out_loc, &din, &dout));
     if (nout > 0 && can_fuse_detect(p, nscrunch)) {
         DetectTail tail;
-        tail.out = (float*)dout;
+        tail.out = (real*)dout;
         tail.mode = mode;
         tail.nscrunch = nscrunch;
         auto steps = build_steps(p, din, nullptr, tail);
@@ -788,7 +842,7 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
         auto steps = build_steps(p, din, (cf*)mid);
         int rc = run_steps(steps, p->stream);
         if (rc == PBH_OK)
-            rc = launch_detect(p->stream, (const cf*)mid, (float*)dout, nout, p->nchan, p->npol, mode, nscrunch);
+            rc = launch_detect(p->stream, (const cf*)mid, (real*)dout, nout, p->nchan, p->npol, mode, nscrunch);
         hipStreamSynchronize(p->stream);
         hipFree(mid);
         PBHCHECK(rc);
@@ -799,12 +853,13 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     return PBH_OK;
 }
 
-int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64, int64_t n, int64_t batch,
-                int inverse, int in_loc, int out_loc) {
+int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_c64, void* out_c64,
+                int64_t n, int64_t batch, int inverse, int in_loc, int out_loc) {
     if (!in_c64 || !out_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     if (n <= 0 || batch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
-    if (!is_pow2(n) || n < 32 || n > kTilePoints)
-        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [32, 16384] in this build");
+    if (!is_pow2(n) || n < PBH_R || n > kTilePoints)
+        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [" + std::to_string(PBH_R) + ", " +
+                                             std::to_string(kTilePoints) + "] for this dtype");
     if (batch > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "batch too large");
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
@@ -814,7 +869,7 @@ int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64,
         std::vector<cf> h(kTwTable);
         for (int i = 0; i < kTwTable; ++i) {
             double a = -2.0 * M_PI * (double)i / (double)kTwTable;
-            h[i] = make_float2((float)cos(a), (float)sin(a));
+            h[i] = make_cf((real)cos(a), (real)sin(a));
         }
         PBHCHECK(dev_alloc(nullptr, (void**)&tw, sizeof(cf) * kTwTable));
         HIPCHECK(hipMemcpy(tw, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice));
@@ -837,7 +892,7 @@ int pbh_fft_c2c(int device, void* hip_stream, const void* in_c64, void* out_c64,
         }
         dout = (cf*)sout;
     }
-    SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (float)(1.0 / (double)n)};
+    SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (real)(1.0 / (double)n)};
     rc = launch_small((int)n, sp, st);
     hipError_t e = hipSuccess;
     if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out_c64, dout, bytes, hipMemcpyDeviceToHost, st);
@@ -992,6 +1047,7 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
     return PBH_OK;
 }
 
+#ifndef PBH_F64
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
     if (!ms_mean || bytes < 16 || iters <= 0) return fail(PBH_ERR_INVALID, "bad argument");
     HIPCHECK(hipSetDevice(device));
@@ -1022,5 +1078,7 @@ int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
     *ms_mean = ms / iters;
     return PBH_OK;
 }
+
+#endif  // !PBH_F64
 
 }  // extern "C"

@@ -1,0 +1,132 @@
+// pbhip_api.cpp -- the public C ABI of include/pbhip.h.  The implementation is compiled twice
+// (pbhip.hip: pbh32_* for complex64 / float32, pbh64_* for complex128 / float64); this file owns
+// the pbh_* symbols and forwards on the plan's dtype.
+#include "../../include/pbhip.h"
+
+#include <string>
+
+#define PBH_DECLARE_IMPL(P)                                                                                     \
+    struct P##plan;                                                                                             \
+    extern "C" {                                                                                                \
+    const char* P##last_error(void);                                                                            \
+    int P##plan_create(P##plan**, int, int64_t, int, int, int, int64_t, int64_t);                               \
+    int P##plan_destroy(P##plan*);                                                                              \
+    int P##plan_set_stream(P##plan*, void*);                                                                    \
+    int P##plan_set_variant(P##plan*, int);                                                                     \
+    int P##plan_info(const P##plan*, pbh_plan_info_t*);                                                         \
+    int P##chirp_generate(P##plan*, double, double, const double*, double);                                     \
+    int P##chirp_upload(P##plan*, const void*, int);                                                            \
+    int P##chirp_download(P##plan*, void*, int);                                                                \
+    int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
+    int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
+    int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
+    int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
+    int P##fft_c2c(int, void*, int, const void*, void*, int64_t, int64_t, int, int, int);                       \
+    int P##plan_profile(P##plan*, const void*, void*, int, float*, int*, const char**);                         \
+    }
+PBH_DECLARE_IMPL(pbh32_)
+PBH_DECLARE_IMPL(pbh64_)
+extern "C" {
+int pbh32_device_count(void);
+const char* pbh32_version(void);
+int pbh32_chirp_function(int, void*, double, int64_t, double, double, double, void*, int);
+int pbh32_copy_bench(int, int64_t, int, float*);
+}
+
+struct pbh_plan {
+    int dtype;
+    void* impl;
+};
+
+// which implementation produced the most recent failure on this thread (-1: this file)
+static thread_local int g_last = 0;
+static thread_local std::string g_err;
+
+static int fail_here(int code, const char* msg) {
+    g_last = -1;
+    g_err = msg;
+    return code;
+}
+static int done(int dtype, int rc) {
+    if (rc != PBH_OK) g_last = dtype;
+    return rc;
+}
+
+#define FORWARD(p, call32, call64)                                            \
+    do {                                                                      \
+        if (!(p)) return fail_here(PBH_ERR_INVALID, "plan is NULL");          \
+        if ((p)->dtype == PBH_C128) return done(PBH_C128, call64);            \
+        return done(PBH_C64, call32);                                         \
+    } while (0)
+#define P32(p) ((pbh32_plan*)(p)->impl)
+#define P64(p) ((pbh64_plan*)(p)->impl)
+
+extern "C" {
+
+int pbh_device_count(void) { return pbh32_device_count(); }
+const char* pbh_version(void) { return pbh32_version(); }
+const char* pbh_last_error(void) {
+    if (g_last == -1) return g_err.c_str();
+    return g_last == PBH_C128 ? pbh64_last_error() : pbh32_last_error();
+}
+
+int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
+                    int64_t crop_start, int64_t crop_stop) {
+    if (!out) return fail_here(PBH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dtype != PBH_C64 && dtype != PBH_C128)
+        return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+    void* impl = nullptr;
+    int rc = dtype == PBH_C128
+                 ? pbh64_plan_create((pbh64_plan**)&impl, device, nsample, nchan, npol, dtype, crop_start, crop_stop)
+                 : pbh32_plan_create((pbh32_plan**)&impl, device, nsample, nchan, npol, dtype, crop_start, crop_stop);
+    if (rc != PBH_OK) return done(dtype, rc);
+    *out = new pbh_plan{dtype, impl};
+    return PBH_OK;
+}
+
+int pbh_plan_destroy(pbh_plan* p) {
+    if (!p) return PBH_OK;
+    int rc = p->dtype == PBH_C128 ? pbh64_plan_destroy(P64(p)) : pbh32_plan_destroy(P32(p));
+    delete p;
+    return rc;
+}
+
+int pbh_plan_set_stream(pbh_plan* p, void* s) { FORWARD(p, pbh32_plan_set_stream(P32(p), s), pbh64_plan_set_stream(P64(p), s)); }
+int pbh_plan_set_variant(pbh_plan* p, int v) { FORWARD(p, pbh32_plan_set_variant(P32(p), v), pbh64_plan_set_variant(P64(p), v)); }
+int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* i) { FORWARD(p, pbh32_plan_info(P32(p), i), pbh64_plan_info(P64(p), i)); }
+int pbh_chirp_generate(pbh_plan* p, double c, double dt, const double* f, double r) {
+    FORWARD(p, pbh32_chirp_generate(P32(p), c, dt, f, r), pbh64_chirp_generate(P64(p), c, dt, f, r));
+}
+int pbh_chirp_upload(pbh_plan* p, const void* c, int loc) { FORWARD(p, pbh32_chirp_upload(P32(p), c, loc), pbh64_chirp_upload(P64(p), c, loc)); }
+int pbh_chirp_download(pbh_plan* p, void* c, int loc) { FORWARD(p, pbh32_chirp_download(P32(p), c, loc), pbh64_chirp_download(P64(p), c, loc)); }
+int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double dt, double fc, double fr, void* out, int loc) {
+    return done(PBH_C64, pbh32_chirp_function(device, stream, coeff, n, dt, fc, fr, out, loc));
+}
+int pbh_dedisperse(pbh_plan* p, const void* in, void* out, int il, int ol) {
+    FORWARD(p, pbh32_dedisperse(P32(p), in, out, il, ol), pbh64_dedisperse(P64(p), in, out, il, ol));
+}
+int pbh_dedisperse_detect(pbh_plan* p, const void* in, void* out, int ns, int mode, int il, int ol) {
+    FORWARD(p, pbh32_dedisperse_detect(P32(p), in, out, ns, mode, il, ol), pbh64_dedisperse_detect(P64(p), in, out, ns, mode, il, ol));
+}
+int pbh_dedisperse_stream(pbh_plan* p, const void* in, int64_t total, void* out, int64_t* nchunk, float* ms) {
+    FORWARD(p, pbh32_dedisperse_stream(P32(p), in, total, out, nchunk, ms), pbh64_dedisperse_stream(P64(p), in, total, out, nchunk, ms));
+}
+int pbh_detect(int device, void* stream, int dtype, const void* in, void* out, int64_t n, int nchan, int npol, int mode,
+               int ns, int il, int ol) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_detect(device, stream, dtype, in, out, n, nchan, npol, mode, ns, il, ol));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_detect(device, stream, dtype, in, out, n, nchan, npol, mode, ns, il, ol));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_fft_c2c(int device, void* stream, int dtype, const void* in, void* out, int64_t n, int64_t batch, int inverse,
+                int il, int ol) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_fft_c2c(device, stream, dtype, in, out, n, batch, inverse, il, ol));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_fft_c2c(device, stream, dtype, in, out, n, batch, inverse, il, ol));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* ms, int* nk, const char** names) {
+    FORWARD(p, pbh32_plan_profile(P32(p), in, out, iters, ms, nk, names), pbh64_plan_profile(P64(p), in, out, iters, ms, nk, names));
+}
+int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms) { return done(PBH_C64, pbh32_copy_bench(device, bytes, iters, ms)); }
+
+}  // extern "C"

@@ -70,12 +70,10 @@ def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_fre
         from . import _hip
         from .device import DeviceArray
         from .transforms.dedispersion import _geometry
-        if z_local.dtype != np.complex64:
-            raise NotImplementedError("the HIP path computes in complex64")
         nsample, nchan, npol = _geometry(z_local)
         on_device = isinstance(z_local.data, DeviceArray)
         dev = z_local.data.device_index if on_device else 0
-        with _hip.Plan(nsample, nchan, npol, start, stop, device=dev, variant=variant) as plan:
+        with _hip.Plan(nsample, nchan, npol, start, stop, device=dev, variant=variant, dtype=z_local.dtype) as plan:
             plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, ref_hz)
             x = z_local.data.contiguous() if on_device else np.ascontiguousarray(z_local.data)
             y = plan.dedisperse(x)

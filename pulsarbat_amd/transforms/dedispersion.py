@@ -127,10 +127,10 @@ def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
     dt = u.to_value(z.dt, u.s)
     ref = _hz(ref_freq)
     ckey = None if chirp is not None else (coeff, dt, freqs.tobytes(), ref)
-    key = (nsample, nchan, npol, crop, dev, variant)
+    key = (nsample, nchan, npol, crop, dev, variant, np.dtype(z.dtype).str)
     ent = _PLANS.pop(key, None)
     if ent is None:
-        plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant)
+        plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant, dtype=z.dtype)
         ent = [plan, object()]
     plan = ent[0]
     if chirp is not None:
@@ -179,10 +179,7 @@ def _prepare(z, DM, ref_freq, chirp, variant):
         raise TypeError("Signal must be a BasebandSignal object.")
     if ref_freq is None:
         ref_freq = z.center_freq
-    if z.dtype != np.complex64:
-        raise NotImplementedError(
-            "the HIP path computes in complex64 (float32), like scipy.fft on complex64 input; "
-            f"got {z.dtype}. Cast with z.data.astype(numpy.complex64) first.")
+    _hip._dtype_code(z.dtype)  # complex64 -> float32 kernels, complex128 -> float64 kernels (as scipy.fft)
     start, stop = _crop_bounds(z, DM, ref_freq)
     c2 = None if chirp is None else _as_2d_chirp(chirp, z)
     plan, on_device = _plan_for(z, DM, ref_freq, (start, stop), chirp=c2, variant=variant)
@@ -237,8 +234,6 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
         raise TypeError("Signal must be a BasebandSignal object.")
     if isinstance(z.data, DeviceArray):
         raise TypeError("coherent_dedispersion_stream takes a host-resident signal")
-    if z.dtype != np.complex64:
-        raise NotImplementedError("the HIP path computes in complex64")
     if ref_freq is None:
         ref_freq = z.center_freq
     head = z[:chunk]

@@ -45,7 +45,11 @@ def test_argument_validation_without_gpu():
     assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 7, 0, 1024) == -2
     assert lib.pbh_plan_destroy(None) == 0
     assert lib.pbh_dedisperse(None, None, None, 0, 0) == -1
-    assert lib.pbh_fft_c2c(0, None, None, None, 1024, 1, 0, 0, 0) == -1
+    assert lib.pbh_fft_c2c(0, None, 0, None, None, 1024, 1, 0, 0, 0) == -1
+    assert lib.pbh_fft_c2c(0, None, 5, None, None, 1024, 1, 0, 0, 0) == -2
+    assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 1, 0, 1024) in (0, -1)  # complex128 plans exist
+    if h.value:
+        lib.pbh_plan_destroy(h)
     if lib.pbh_device_count() == 0:
         assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 0, 0, 1024) == -1
         assert b"not present" in lib.pbh_last_error()

@@ -258,9 +258,6 @@ def test_arbitrary_length_stream_and_detect():
 
 
 def test_errors():
-    z128 = make_signal(orc.synthetic_block((1024, 2), 1).astype(np.complex128), 1e6, 1e9)
-    with pytest.raises(NotImplementedError):
-        pb.coherent_dedispersion(z128, pb.DM(1.0))
     zz = make_signal(orc.synthetic_block((1024, 2), 1), 1e6, 1e9)
     with pytest.raises(NotImplementedError):
         pb.coherent_dedispersion(zz, pb.DM(1.0), chirp=np.ones((1024, 2, 2), np.complex64))
@@ -342,3 +339,98 @@ def test_stream_overlap_save(shape, chunk, dm):
                            for k in range(nchunk)], axis=0)
     assert series_errors(y, want)[0] < RTOL_L2
     assert abs((y.start_time - z.start_time).to_value(u.s) - start / sr) < 1e-12
+
+
+# ---- complex128 (float64 kernels): the reference accepts both dtypes (core.py:742) and keeps
+# dtype in = dtype out (tests/test_fft.py:53-54); its own tests feed complex128 ----------------------
+# With the HIP-generated chirp the bound is set by complex64 rounding of the chirp (the reference
+# rounds it too, dedispersion.py:23): the float64 phase differs from numpy's by ~1 ulp, which flips
+# the last float32 bit of a few chirp samples (6e-8 each).  With the oracle's own chirp uploaded the
+# float64 kernels agree with pocketfft to ~1e-15.
+RTOL_F64 = 1e-9
+RTOL_F64_SAME_CHIRP = 2e-14
+
+
+def check128(shape, dm, sr=1e6, fc=1e9, seed=2, variant="auto", device=False):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5
+    z = make_signal(x, sr, fc, start_time=pb.Time(56000.0, format="mjd"))
+    zz = z.to_device() if device else z
+    y = pb.coherent_dedispersion(zz, pb.DM(dm), variant=variant)
+    yr, start, stop = orc.coherent_dedispersion(x, dm, sr, fc)
+    assert y.dtype == np.complex128 and type(y.data) is type(zz.data)
+    assert y.shape == yr.shape
+    l2, mx = series_errors(y, yr)
+    assert l2 < RTOL_F64, f"relative L2 {l2:.2e}"
+    chirp = orc.chirp_from_signal(dm, x.shape, sr, fc)
+    y2 = pb.coherent_dedispersion(zz, pb.DM(dm), variant=variant, chirp=chirp)
+    l2, mx = series_errors(y2, yr)
+    assert l2 < RTOL_F64_SAME_CHIRP, f"relative L2 with the oracle's chirp {l2:.2e}"
+    return y
+
+
+@pytest.mark.parametrize("shape,dm", [((16, 2), 0.001), ((4096, 4, 2), 5.0), ((8192, 4), 50.0), ((1 << 13, 3, 2), 10.0),
+                                      ((1 << 14, 2, 2), 10.0), ((1 << 16, 2, 2), 20.0), ((1 << 18, 2), 20.0),
+                                      ((1 << 20, 1, 2), 40.0)])
+def test_c128_parity(shape, dm):
+    check128(shape, dm)
+
+
+@pytest.mark.parametrize("variant", ["direct3", "planar5", "block3"])
+def test_c128_variants(variant):
+    check128((1 << 17, 4, 2), 20.0, variant=variant, device=True)
+
+
+@pytest.mark.parametrize("shape,dm", [((1000, 2), 1.0), ((30000, 2, 2), 10.0), ((65537, 1), 5.0)])
+def test_c128_arbitrary_lengths(shape, dm):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    z = make_signal(x, 1e6, 1e9)
+    y = pb.coherent_dedispersion(z, pb.DM(dm))
+    yr, _, _ = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    assert y.dtype == np.complex128 and series_errors(y, yr)[0] < RTOL_F64
+
+
+@pytest.mark.parametrize("seed", [4, 8, 15, 16, 23, 42])
+def test_c128_reversibility_reference_tolerance(seed):
+    """reference tests/test_dedispersion.py:73-98 at its own tolerance (atol 3e-8, complex128 data)."""
+    import scipy.signal
+    ref, sr, dm = 600e6, 400e6, 0.01
+    N, M = 2 ** 18, 2 ** 12
+    R = np.random.default_rng(seed=seed)
+    x = R.standard_normal(N) + 1j * R.standard_normal(N)
+    x *= np.exp(-(((np.arange(N) - N // 2) / M) ** 2))
+    sos = scipy.signal.butter(10, 0.45, "lowpass", fs=1.0, output="sos")
+    x = scipy.signal.sosfilt(sos, x).reshape(-1, 1)
+    sig = make_signal(x, sr, ref, start_time=pb.Time(56000.0, format="mjd"))
+    temp = pb.coherent_dedispersion(sig, pb.DM(dm))          # length 2^18 - crop: not a power of two
+    sig2 = pb.coherent_dedispersion(temp, -pb.DM(dm))        # -> Bluestein, exactly as the reference chains them
+    toffset = sig2.start_time - sig.start_time
+    noffset = int(np.rint((toffset * sig.sample_rate).to_value(u.one)))
+    sig1 = sig[noffset:noffset + len(sig2)]
+    res = np.array(sig1) - np.array(sig2)
+    assert np.allclose(res, 0, atol=3e-8)
+
+
+def test_c128_detect_and_fft():
+    import scipy.fft
+    rng = np.random.default_rng(9)
+    shape = (1 << 15, 2, 2)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    z = make_signal(x, 1e6, 1e9)
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(10.0))
+    i = y.to_intensity()
+    assert i.dtype == np.float64                      # reference tests/test_radio_signal.py:142-172
+    assert np.allclose(np.asarray(i.data), orc.to_intensity(np.asarray(y)), rtol=1e-12)
+    s = y.to_stokes()
+    assert s.dtype == np.float64
+    assert np.allclose(np.asarray(s.data), orc.to_stokes(np.asarray(y), "linear"), rtol=1e-10, atol=1e-12)
+    got, start = pb.dedisperse_detect(z, pb.DM(10.0), mode="I", nscrunch=64)
+    yr, s0, _ = orc.coherent_dedispersion(x, 10.0, 1e6, 1e9)
+    assert got.dtype == np.float64 and start == s0
+    assert np.allclose(got, orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], 64), rtol=1e-11)
+    d = pb.DeviceArray.from_host(x[:4096].reshape(4096, -1).copy())
+    for name in ("fft", "ifft"):
+        g = getattr(pb.fft, name)(d, axis=0)
+        w = getattr(scipy.fft, name)(x[:4096].reshape(4096, -1), axis=0)
+        assert g.dtype == np.complex128 and np.linalg.norm(np.asarray(g) - w) / np.linalg.norm(w) < 1e-13
