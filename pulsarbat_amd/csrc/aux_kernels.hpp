@@ -361,6 +361,28 @@ __global__ __launch_bounds__(256) void k_bs_post(const cf* __restrict__ conv, co
     }
 }
 
+// plain transforms through the same ring (pbh_fft_c2c for lengths beyond one tile / not 2^k):
+//   forward: X[k] = b[k] * conv[k]            with a = x * b
+//   inverse: x[n] = conj(b[n] * conv[n]) / N  with a = conj(X) * b
+__global__ __launch_bounds__(256) void k_bs_pre_conj(const cf* __restrict__ x, const cf* __restrict__ b,
+                                                     cf* __restrict__ a, int64_t N, int64_t L, int S) {
+    const int64_t total = L * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / S;
+        cf v = make_cf(0, 0);
+        if (n < N) v = cmul(cconj(x[e]), b[n]);
+        a[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_bs_post_fft(const cf* __restrict__ conv, const cf* __restrict__ b,
+                                                     cf* __restrict__ out, int64_t N, int S, int inverse, real scale) {
+    const int64_t total = N * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const cf v = cmul(conv[e], b[e / S]);
+        out[e] = inverse ? make_cf(v.x * scale, -v.y * scale) : v;
+    }
+}
+
 #ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {

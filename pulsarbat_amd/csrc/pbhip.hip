@@ -90,6 +90,7 @@ struct pbh_plan {
     int tw_shift = 0;
     double* chan_freq = nullptr;
     // Bluestein (nsample not a power of two, or < 32): two runs of a power-of-two sub-plan
+    bool plain_fft = false;     // plan backs pbh_fft_c2c: Bluestein ring for every length, no chirp buffer
     int64_t bsL = 0;            // ring length, power of two >= 2N-1; 0 = not a Bluestein plan
     pbh_plan* sub = nullptr;    // (bsL, 1 chan, S "pols") plan whose chirp is FFT_L(wrapped conj b)/L
     cf* bs_b = nullptr;         // b[n] = exp(-i pi n^2/N)
@@ -467,8 +468,16 @@ const char* pbh_last_error(void) { return g_err.c_str(); }
 
 const char* pbh_version(void) { return "pbhip 0.1.0 (gfx950)"; }
 
+static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
+                       int64_t crop_start, int64_t crop_stop, bool plain_fft);
+
 int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
                     int64_t crop_start, int64_t crop_stop) {
+    return create_plan(out, device, nsample, nchan, npol, dtype, crop_start, crop_stop, false);
+}
+
+static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
+                       int64_t crop_start, int64_t crop_stop, bool plain_fft) {
     if (!out) return fail(PBH_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
@@ -477,7 +486,7 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
 #else
     if (dtype != PBH_C64) return fail(PBH_ERR_INVALID, "dtype mismatch (float32 build)");
 #endif
-    const bool pow2 = is_pow2(nsample) && nsample >= PBH_R;
+    const bool pow2 = is_pow2(nsample) && nsample >= PBH_R && !plain_fft;
     if (nsample < 2 || nsample > (1LL << 28) || (!pow2 && nsample > (1LL << 27)))
         return fail(PBH_ERR_UNSUPPORTED, "nsample must be in [2, 2^28] (powers of two) or [2, 2^27] (other lengths); got " +
                                              std::to_string(nsample));
@@ -491,6 +500,7 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
 
     pbh_plan* p = new pbh_plan();
     p->device = device;
+    p->plain_fft = plain_fft;
     p->N = nsample;
     p->nchan = nchan;
     p->npol = npol;
@@ -538,7 +548,8 @@ int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int 
         if (hipMemcpy(p->tw16k, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(PBH_ERR_HIP, "hipMemcpy(tw16k) failed"));
     }
-    if ((rc = dev_alloc(p, (void**)&p->chirp, sizeof(cf) * (size_t)nchan * nsample)) != PBH_OK) return bail(rc);
+    if (!plain_fft && (rc = dev_alloc(p, (void**)&p->chirp, sizeof(cf) * (size_t)nchan * nsample)) != PBH_OK)
+        return bail(rc);
     if ((rc = dev_alloc(p, (void**)&p->chan_freq, sizeof(double) * nchan)) != PBH_OK) return bail(rc);
     if (p->N1 > 1) {
         // W_N^p = hi[p >> shift] * lo[p & mask], float64
@@ -853,19 +864,55 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     return PBH_OK;
 }
 
+// Lengths beyond one tile, or not a power of two: Bluestein ring as a plain transform
+// (forward X = b * conv(x b); inverse x = conj(b * conv(conj(X) b)) / n).  Plans are cached per thread.
+static int fft_c2c_ring(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
+    struct Entry { int device; int64_t n, batch; pbh_plan* plan; };
+    static thread_local Entry cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+    static thread_local int next = 0;
+    pbh_plan* p = nullptr;
+    for (auto& e : cache)
+        if (e.plan && e.device == device && e.n == n && e.batch == batch) p = e.plan;
+    if (!p) {
+#ifdef PBH_F64
+        const int dt = PBH_C128;
+#else
+        const int dt = PBH_C64;
+#endif
+        PBHCHECK(create_plan(&p, device, n, 1, (int)batch, dt, 0, n, true));
+        Entry& e = cache[next];
+        next ^= 1;
+        if (e.plan) pbh_plan_destroy(e.plan);
+        e = Entry{device, n, batch, p};
+    }
+    const int64_t L = p->bsL;
+    const int S = p->S;
+    auto grid = [](int64_t m) { int64_t g = (m + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
+    if (inverse)
+        hipLaunchKernelGGL(k_bs_pre_conj, dim3(grid(L * S)), dim3(256), 0, st, din, (const cf*)p->bs_b, p->bs_a, n, L, S);
+    else
+        hipLaunchKernelGGL(k_bs_pre, dim3(grid(L * S)), dim3(256), 0, st, din, (const cf*)p->bs_b, p->bs_a, n, L, S);
+    HIPCHECK(hipGetLastError());
+    auto steps = build_steps(p->sub, p->bs_a, p->bs_conv);
+    PBHCHECK(run_steps(steps, st));
+    hipLaunchKernelGGL(k_bs_post_fft, dim3(grid(n * S)), dim3(256), 0, st, (const cf*)p->bs_conv, (const cf*)p->bs_b, dout,
+                       n, S, inverse, (real)(1.0 / (double)n));
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
 int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_c64, void* out_c64,
                 int64_t n, int64_t batch, int inverse, int in_loc, int out_loc) {
     if (!in_c64 || !out_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     if (n <= 0 || batch <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
-    if (!is_pow2(n) || n < PBH_R || n > kTilePoints)
-        return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be a power of two in [" + std::to_string(PBH_R) + ", " +
-                                             std::to_string(kTilePoints) + "] for this dtype");
     if (batch > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "batch too large");
+    if (n == 1 || n > (1LL << 27)) return fail(PBH_ERR_UNSUPPORTED, "pbh_fft_c2c: n must be in [2, 2^27]");
+    const bool one_tile = is_pow2(n) && n >= PBH_R && n <= kTilePoints;
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
     static thread_local cf* tw = nullptr;
     static thread_local int tw_dev = -1;
-    if (!tw || tw_dev != device) {
+    if (one_tile && (!tw || tw_dev != device)) {
         std::vector<cf> h(kTwTable);
         for (int i = 0; i < kTwTable; ++i) {
             double a = -2.0 * M_PI * (double)i / (double)kTwTable;
@@ -892,8 +939,12 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
         }
         dout = (cf*)sout;
     }
-    SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (real)(1.0 / (double)n)};
-    rc = launch_small((int)n, sp, st);
+    if (one_tile) {
+        SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (real)(1.0 / (double)n)};
+        rc = launch_small((int)n, sp, st);
+    } else {
+        rc = fft_c2c_ring(device, st, din, dout, n, batch, inverse);
+    }
     hipError_t e = hipSuccess;
     if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out_c64, dout, bytes, hipMemcpyDeviceToHost, st);
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) {

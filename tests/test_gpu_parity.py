@@ -434,3 +434,22 @@ def test_c128_detect_and_fft():
         g = getattr(pb.fft, name)(d, axis=0)
         w = getattr(scipy.fft, name)(x[:4096].reshape(4096, -1), axis=0)
         assert g.dtype == np.complex128 and np.linalg.norm(np.asarray(g) - w) / np.linalg.norm(w) < 1e-13
+
+
+@pytest.mark.parametrize("n,batch", [(1 << 15, 6), (1 << 18, 2), (1000, 5), (12345, 3), (65537, 1), (20, 4)])
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_fft_dispatch_any_length(n, batch, dtype):
+    """pb.fft.fft / ifft on device arrays for lengths beyond one tile and non powers of two
+    (reference tests/test_fft.py:41-61: same container type, same dtype, allclose to scipy)."""
+    import scipy.fft
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((n, batch)) + 1j * rng.standard_normal((n, batch))).astype(dtype)
+    d = pb.DeviceArray.from_host(x)
+    tol = 2e-6 if dtype == np.complex64 else 1e-12
+    for name in ("fft", "ifft"):
+        got = getattr(pb.fft, name)(d, axis=0)
+        want = getattr(scipy.fft, name)(x, axis=0)
+        assert type(got) is type(d) and got.dtype == want.dtype
+        assert np.linalg.norm(np.asarray(got) - want) / np.linalg.norm(want) < tol
+    back = pb.fft.ifft(pb.fft.fft(d, axis=0), axis=0)
+    assert np.linalg.norm(np.asarray(back) - x) / np.linalg.norm(x) < 2 * tol
