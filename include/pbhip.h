@@ -141,6 +141,14 @@ int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* ou
 int pbh_fft_c2c(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t n,
                 int64_t batch, int inverse, int in_loc, int out_loc);
 
+/* contrib.stft / istft (pulsarbat/contrib/misc.py:17-93; boxcar window, no overlap, nfft = nperseg): the
+ * critically sampled channeliser.  stft : in (nseg*nperseg, nchan, inner) time-ordered -> out
+ * (nseg, nchan*nperseg, inner) with out[g, c*n + (k + n/2) % n, e] = FFT_k(in[g*n + t, c, e]) / n
+ * (fft, fftshift, /nperseg of misc.py:47-52).  inverse != 0 is istft, its exact inverse (misc.py:83-91).
+ * Any nperseg >= 1; powers of two up to one tile run a single fused kernel.                               */
+int pbh_stft(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nseg, int nperseg,
+             int nchan, int inner, int inverse, int in_loc, int out_loc);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Runs the plan's kernel sequence `iters` times on device-resident in/out with hipEvents between the
  * kernels (on the plan's stream) and returns the mean milliseconds of each kernel.                    */

@@ -196,3 +196,26 @@ def synthetic_block(shape, seed):
     re = rng.standard_normal(shape, dtype=np.float32)
     im = rng.standard_normal(shape, dtype=np.float32)
     return ((re + 1j * im) * np.float32(2 ** -0.5)).astype(np.complex64)
+
+
+def stft(x, nperseg):
+    """pulsarbat/contrib/misc.py:41-52 (stft) on the data array: trim, reshape, swap, fft, fftshift,
+    reshape, / nperseg.  ``x`` is (nsample, nchan, ...)."""
+    n = int(nperseg)
+    x = x[: len(x) - len(x) % n]
+    y = x.reshape((-1, n) + x.shape[1:]).swapaxes(1, 2)
+    y = scipy.fft.fft(y, axis=2, n=n)
+    y = np.fft.fftshift(y, axes=(2,))
+    y = y.reshape((y.shape[0], -1) + y.shape[3:])
+    return y / n
+
+
+def istft(y, nperseg):
+    """pulsarbat/contrib/misc.py:80-91 (istft) on the data array ``y`` (nseg, nchan*nperseg, ...)."""
+    n = int(nperseg)
+    x = y.reshape((len(y), -1, n) + y.shape[2:]) * n
+    x = x.swapaxes(1, 2)
+    x = np.fft.ifftshift(x, axes=(1,))
+    x = scipy.fft.ifft(x, axis=1, n=n)
+    x = x[:, :n]
+    return x.reshape((-1,) + x.shape[2:])

@@ -17,7 +17,8 @@ from .device import DeviceArray
 from . import transforms
 from .transforms import *
 from . import fft
+from . import contrib
 
-__all__ = ["fft", "units", "Time", "DeviceArray", "InvalidSignalError"]
+__all__ = ["fft", "contrib", "units", "Time", "DeviceArray", "InvalidSignalError"]
 __all__.extend(core.__all__)
 __all__.extend(transforms.__all__)

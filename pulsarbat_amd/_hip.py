@@ -72,6 +72,8 @@ SIGNATURES = {
                              C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                               C.c_int, C.c_int]),
+    "pbh_stft": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                           C.c_int, C.c_int, C.c_int]),
     "pbh_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "pbh_copy_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
@@ -331,6 +333,37 @@ def fft_c2c(x, inverse=False):
     pin, lin = _ptr_loc(x)
     pout, lout = _ptr_loc(out)
     _check(lib().pbh_fft_c2c(dev, stream, code, pin, pout, int(n), batch, int(bool(inverse)), lin, lout))
+    return out
+
+
+def stft(x, nperseg, inverse=False):
+    """contrib.stft / istft core on (nseg*nperseg, nchan, ...) [stft] or (nseg, nchan*nperseg, ...) [istft] data."""
+    from .device import DeviceArray
+    _require_device()
+    code = _dtype_code(x.dtype)
+    n = int(nperseg)
+    inner = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    if inverse:
+        if x.shape[1] % n:
+            raise ValueError("channel axis is not a multiple of nperseg")
+        nseg, nchan = x.shape[0], x.shape[1] // n
+        oshape = (nseg * n, nchan) + tuple(x.shape[2:])
+    else:
+        if x.shape[0] % n:
+            raise ValueError("time axis is not a multiple of nperseg")
+        nseg, nchan = x.shape[0] // n, x.shape[1]
+        oshape = (nseg, nchan * n) + tuple(x.shape[2:])
+    if isinstance(x, DeviceArray):
+        x = x.contiguous()
+        out = DeviceArray.empty(oshape, x.dtype, device=x.device_index)
+        dev, stream = x.device_index, _stream_ptr(x.device_index)
+    else:
+        x = np.ascontiguousarray(x)
+        out = np.empty(oshape, dtype=x.dtype)
+        dev, stream = 0, C.c_void_p(0)
+    pin, lin = _ptr_loc(x)
+    pout, lout = _ptr_loc(out)
+    _check(lib().pbh_stft(dev, stream, code, pin, pout, int(nseg), n, int(nchan), inner, int(bool(inverse)), lin, lout))
     return out
 
 

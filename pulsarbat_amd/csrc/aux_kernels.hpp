@@ -383,6 +383,48 @@ __global__ __launch_bounds__(256) void k_bs_post_fft(const cf* __restrict__ conv
     }
 }
 
+// stft / istft through the Bluestein ring (nperseg not a power of two, or beyond one tile).  The ring
+// batch is B = nseg*S: column beta = g*S + s.  Time side: element (g, t, s) at g*N*S + t*S + s.
+// Channelised side: (g, c, k, e) at g*N*S + (c*N + (k + N/2) % N)*E + e, s = c*E + e.
+__device__ __forceinline__ int64_t seg_time_off(int64_t g, int64_t t, int s, int64_t N, int S) {
+    return (g * N + t) * S + s;
+}
+__device__ __forceinline__ int64_t seg_chan_off(int64_t g, int64_t k, int s, int64_t N, int S, int E) {
+    const int c = s / E, e = s - c * E;
+    return g * N * S + ((int64_t)c * N + (k + N / 2) % N) * E + e;
+}
+// a[(n, beta)] = n < N ? src(n, beta) * b[n] : 0, with src = x (stft) or conj(Y) read through the shift (istft)
+__global__ __launch_bounds__(256) void k_seg_pre(const cf* __restrict__ in, const cf* __restrict__ b,
+                                                 cf* __restrict__ a, int64_t N, int64_t L, int S, int E,
+                                                 int64_t nseg, int inverse) {
+    const int64_t B = nseg * S, total = L * B;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / B, beta = idx - n * B;
+        const int64_t g = beta / S;
+        const int s = (int)(beta - g * S);
+        cf v = make_cf(0, 0);
+        if (n < N) {
+            if (inverse) v = cmul(cconj(in[seg_chan_off(g, n, s, N, S, E)]), b[n]);
+            else v = cmul(in[seg_time_off(g, n, s, N, S)], b[n]);
+        }
+        a[idx] = v;
+    }
+}
+// stft : out(chan side)[k] = b[k] * conv[k] / N;   istft: out(time side)[t] = conj(b[t] * conv[t])
+__global__ __launch_bounds__(256) void k_seg_post(const cf* __restrict__ conv, const cf* __restrict__ b,
+                                                  cf* __restrict__ out, int64_t N, int S, int E, int64_t nseg,
+                                                  int inverse, real scale) {
+    const int64_t B = nseg * S, total = N * B;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / B, beta = idx - n * B;
+        const int64_t g = beta / S;
+        const int s = (int)(beta - g * S);
+        const cf v = cmul(conv[idx], b[n]);
+        if (inverse) out[seg_time_off(g, n, s, N, S)] = make_cf(v.x, -v.y);
+        else out[seg_chan_off(g, n, s, N, S, E)] = make_cf(v.x * scale, v.y * scale);
+    }
+}
+
 #ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {

@@ -429,6 +429,13 @@ struct SmallParams {
     int64_t crop_start, crop_stop;
     int dir;      // plain-FFT mode only: -1 forward, +1 inverse
     real scale;   // plain-FFT mode only
+    // contrib.stft / istft (pulsarbat/contrib/misc.py:17-93): blockIdx.y = segment, a segment is an
+    // (M, S) block of the time-ordered side; the channelised side is (nchan*M, E) per segment with
+    // bin k of channel c at row c*M + ((k + M/2) % M)  (fftshift; for M = 2^m that is k ^ M/2).
+    int seg_mode = 0;  // 0: plain block;  1: stft (shifted store, * scale);  2: istft (shifted load)
+    int E = 1;         // inner elements per channel (npol * ...): series q = c*E + e
+    int segs = 1;      // segments per tile (when the tile's F columns exceed S): column f = (f / S, f % S)
+    int64_t nseg = 1;  // total segments (tail tiles are masked)
 };
 
 template <int M, int R>
@@ -441,23 +448,43 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
 
     const int tid = threadIdx.x;
     const int f = tid % F, tau = tid / F;
-    const int64_t q = (int64_t)blockIdx.x * F + f;
-    const bool valid = q < p.S;
+    // column -> (segment within the tile, series).  Plain blocks and large M: one segment per tile
+    // and blockIdx.x walks the series; small M with segments: the tile spans `segs` whole segments.
+    int sl = 0;
+    int64_t q = (int64_t)blockIdx.x * F + f;
+    bool valid = q < p.S;
+    if (p.segs > 1) {
+        sl = f / p.S;
+        q = f - sl * p.S;
+        valid = sl < p.segs && (int64_t)blockIdx.y * p.segs + sl < p.nseg;
+    }
     const int64_t qq = valid ? q : 0;
 
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
-    // buffer addressing: wave-uniform descriptors over the whole block, per-lane offset
-    // (tau*S + q)*8, scalar step MR*S*8; invalid lanes get an out-of-range offset (reads 0, writes dropped)
-    const uint32_t in_bytes = (uint32_t)((int64_t)M * p.S * sizeof(cf));
-    const rsrc_t ri = make_rsrc(p.in, in_bytes);
+    // buffer addressing: wave-uniform descriptors over the tile's segments, per-lane offset
+    // (sl*M*S + tau*S + q)*8, scalar step MR*S*8; invalid lanes get an out-of-range offset
+    // (reads return 0, writes are dropped)
+    const uint32_t in_bytes = (uint32_t)((int64_t)p.segs * M * p.S * sizeof(cf));
+    const int64_t seg_off = (int64_t)blockIdx.y * p.segs * M * p.S;  // segments are consecutive (M, S) blocks
+    const rsrc_t ri = make_rsrc(p.in + seg_off, in_bytes);
     const int oob = 0x7ffffff0;
-    const int voff = valid ? (int)((tau * (int64_t)p.S + qq) * sizeof(cf)) : oob;
+    const int64_t lane_seg = (int64_t)sl * M * p.S;
+    const int voff = valid ? (int)((lane_seg + tau * (int64_t)p.S + qq) * sizeof(cf)) : oob;
     const int step = MR * p.S * (int)sizeof(cf);
+    // channelised-side addressing: row r of series q = (c, e) at ((c*M + r)*E + e)
+    const int cq = (int)(qq / p.E), eq = (int)(qq - (int64_t)cq * p.E);
+    const int voff_ch = valid ? (int)((lane_seg + ((int64_t)cq * M + tau) * p.E + eq) * sizeof(cf)) : oob;
+    const int step_ch = MR * p.E * (int)sizeof(cf);
     cf v[R];
+    if (p.seg_mode == 2) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff, i * step);
+        for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff_ch, (i ^ (R / 2)) * step_ch);  // ifftshift
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff, i * step);
+    }
 
     if (p.chirp) {
         const rsrc_t rc = make_rsrc(p.chirp + (qq / p.npol) * (int64_t)M, (uint32_t)(M * sizeof(cf)));
@@ -473,14 +500,21 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i] = make_cf(v[i].x * p.scale, v[i].y * p.scale);
     }
+    if (p.seg_mode == 1) {  // stft: fftshift + 1/M on the way out
+        const rsrc_t rs = make_rsrc(p.out + seg_off, in_bytes);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            buf_store(rs, voff_ch, (i ^ (R / 2)) * step_ch, make_cf(v[i].x * p.scale, v[i].y * p.scale));
+        return;
+    }
     // output rows [crop_start, crop_stop) -> out row (row - crop_start)
     const int64_t nout_rows = p.crop_stop - p.crop_start;
-    const rsrc_t ro = make_rsrc(p.out, (uint32_t)(nout_rows * p.S * sizeof(cf)));
+    const rsrc_t ro = make_rsrc(p.out + seg_off, (uint32_t)(((int64_t)(p.segs - 1) * M + nout_rows) * p.S * sizeof(cf)));
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int64_t row = tau + i * MR;
         const bool keep = valid && row >= p.crop_start && row < p.crop_stop;
-        const int off = keep ? (int)(((row - p.crop_start) * p.S + qq) * sizeof(cf)) : oob;
+        const int off = keep ? (int)((lane_seg + (row - p.crop_start) * p.S + qq) * sizeof(cf)) : oob;
         buf_store(ro, off, 0, v[i]);
     }
 }

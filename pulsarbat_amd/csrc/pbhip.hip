@@ -129,7 +129,8 @@ static int block_lane_order() {
 
 template <typename K, typename P>
 static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads, hipStream_t st,
-                              size_t lds = lds_tile_bytes<true>() /* 132 KiB: tile + 1 pad slot per 32 */) {
+                              size_t lds = lds_tile_bytes<true>() /* 132 KiB: tile + 1 pad slot per 32 */,
+                              unsigned grid_y = 1) {
     static thread_local const void* configured[128];
     static thread_local int nconf = 0;
     bool seen = false;
@@ -139,7 +140,7 @@ static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads
         if (nconf < 128) configured[nconf++] = (const void*)kernel;
     }
     if (tiles <= 0 || tiles > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "tile count out of range");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(threads), lds, st, prm);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, grid_y), dim3(threads), lds, st, prm);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -205,13 +206,14 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
 }
 
-static int launch_small(int M, const SmallParams& prm, hipStream_t st) {
+static int launch_small(int M, const SmallParams& prm, hipStream_t st, int64_t nseg = 1) {
     const int F = kTilePoints / M;
+    if (nseg < 1 || nseg > 65535) return fail(PBH_ERR_UNSUPPORTED, "segment count out of range for one launch");
     if ((int64_t)M * prm.S * (int64_t)sizeof(cf) > 0x7fffffffLL)
         return fail(PBH_ERR_UNSUPPORTED, "single-tile block larger than 2 GiB (too many series)");
-    const int64_t tiles = ((int64_t)prm.S + F - 1) / F;
+    const int64_t tiles = prm.segs > 1 ? 1 : ((int64_t)prm.S + F - 1) / F;
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_small<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st);
+#define X(m) case m: return launch_tile_kernel(k_small<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>(), (unsigned)nseg);
         FOR_ALL_M(X)
 #undef X
     }
@@ -866,25 +868,35 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
 
 // Lengths beyond one tile, or not a power of two: Bluestein ring as a plain transform
 // (forward X = b * conv(x b); inverse x = conj(b * conv(conj(X) b)) / n).  Plans are cached per thread.
-static int fft_c2c_ring(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
+// per-thread cache of plain-transform ring plans (n points, `batch` columns)
+static int ring_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
     struct Entry { int device; int64_t n, batch; pbh_plan* plan; };
     static thread_local Entry cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
     static thread_local int next = 0;
-    pbh_plan* p = nullptr;
     for (auto& e : cache)
-        if (e.plan && e.device == device && e.n == n && e.batch == batch) p = e.plan;
-    if (!p) {
+        if (e.plan && e.device == device && e.n == n && e.batch == batch) {
+            *out = e.plan;
+            return PBH_OK;
+        }
+    if (batch > 0x7fffffffLL) return fail(PBH_ERR_UNSUPPORTED, "too many columns for one ring plan");
 #ifdef PBH_F64
-        const int dt = PBH_C128;
+    const int dt = PBH_C128;
 #else
-        const int dt = PBH_C64;
+    const int dt = PBH_C64;
 #endif
-        PBHCHECK(create_plan(&p, device, n, 1, (int)batch, dt, 0, n, true));
-        Entry& e = cache[next];
-        next ^= 1;
-        if (e.plan) pbh_plan_destroy(e.plan);
-        e = Entry{device, n, batch, p};
-    }
+    pbh_plan* p = nullptr;
+    PBHCHECK(create_plan(&p, device, n, 1, (int)batch, dt, 0, n, true));
+    Entry& e = cache[next];
+    next ^= 1;
+    if (e.plan) pbh_plan_destroy(e.plan);
+    e = Entry{device, n, batch, p};
+    *out = p;
+    return PBH_OK;
+}
+
+static int fft_c2c_ring(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
+    pbh_plan* p = nullptr;
+    PBHCHECK(ring_plan(device, n, batch, &p));
     const int64_t L = p->bsL;
     const int S = p->S;
     auto grid = [](int64_t m) { int64_t g = (m + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
@@ -955,6 +967,101 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     if (sout) hipFree(sout);
     if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_fft_c2c: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+// ---- contrib.stft / istft (pulsarbat/contrib/misc.py:17-93): boxcar window, no overlap, nfft = nperseg --------
+// stft : in (nseg*n, nchan, E) time-ordered  -> out (nseg, nchan*n, E), out[g, c*n + (k + n/2) % n, e] = FFT_k / n
+// istft: in (nseg, nchan*n, E) channelised   -> out (nseg*n, nchan, E)   (exact inverse)
+int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, void* out, int64_t nseg, int nperseg,
+                 int nchan, int inner, int inverse, int in_loc, int out_loc) {
+    if (!in || !out) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nseg <= 0 || nperseg <= 0 || nchan <= 0 || inner <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    const int64_t S = (int64_t)nchan * inner, n = nperseg;
+    if (S > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "too many series");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t bytes = sizeof(cf) * (size_t)nseg * n * S;
+    const cf* din = (const cf*)in;
+    cf* dout = (cf*)out;
+    void *stg_in = nullptr, *stg_out = nullptr;
+    int rc = PBH_OK;
+    if (in_loc == PBH_HOST) {
+        PBHCHECK(dev_alloc(nullptr, &stg_in, bytes));
+        hipMemcpyAsync(stg_in, in, bytes, hipMemcpyHostToDevice, st);
+        din = (const cf*)stg_in;
+    }
+    if (out_loc == PBH_HOST) {
+        if ((rc = dev_alloc(nullptr, &stg_out, bytes)) != PBH_OK) {
+            if (stg_in) hipFree(stg_in);
+            return rc;
+        }
+        dout = (cf*)stg_out;
+    }
+    if (n == 1) {
+        // a one-point transform is the identity; both layouts coincide
+        hipError_t e1 = hipMemcpyAsync(dout, din, bytes, hipMemcpyDeviceToDevice, st);
+        if (e1 != hipSuccess) rc = fail(PBH_ERR_HIP, "hipMemcpyAsync failed");
+    } else if (is_pow2(n) && n >= PBH_R && n <= kTilePoints) {
+        static thread_local cf* tw = nullptr;
+        static thread_local int tw_dev = -1;
+        if (!tw || tw_dev != device) {
+            std::vector<cf> h(kTwTable);
+            for (int i = 0; i < kTwTable; ++i) {
+                double a = -2.0 * M_PI * (double)i / (double)kTwTable;
+                h[i] = make_cf((real)cos(a), (real)sin(a));
+            }
+            rc = dev_alloc(nullptr, (void**)&tw, sizeof(cf) * kTwTable);
+            if (rc == PBH_OK && hipMemcpy(tw, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(PBH_ERR_HIP, "hipMemcpy(twiddles) failed");
+            tw_dev = device;
+        }
+        if (rc == PBH_OK) {
+            // a tile holds F = tile/n columns: with F > S it spans F/S whole segments; grid.y walks the
+            // segment groups, at most 65535 per launch
+            const int64_t F = kTilePoints / n;
+            const int segs = F > S ? (int)(F / S) : 1;
+            const int64_t per_launch = 65535LL * segs;
+            for (int64_t g0 = 0; g0 < nseg && rc == PBH_OK; g0 += per_launch) {
+                const int64_t cnt = nseg - g0 < per_launch ? nseg - g0 : per_launch;
+                SmallParams sp{din + g0 * n * S, dout + g0 * n * S, nullptr, tw, (int)S, 1, 0, n, inverse ? +1 : -1,
+                               inverse ? (real)1 : (real)(1.0 / (double)n)};
+                sp.seg_mode = inverse ? 2 : 1;
+                sp.E = inner;
+                sp.segs = segs;
+                sp.nseg = cnt;
+                rc = launch_small((int)n, sp, st, (cnt + segs - 1) / segs);
+            }
+        }
+    } else if (n > (1LL << 27)) {
+        rc = fail(PBH_ERR_UNSUPPORTED, "nperseg too large");
+    } else {
+        pbh_plan* p = nullptr;
+        rc = ring_plan(device, n, nseg * S, &p);
+        if (rc == PBH_OK) {
+            const int64_t L = p->bsL;
+            auto grid = [](int64_t m) { int64_t g = (m + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
+            hipLaunchKernelGGL(k_seg_pre, dim3(grid(L * nseg * S)), dim3(256), 0, st, din, (const cf*)p->bs_b, p->bs_a, n, L,
+                               (int)S, inner, nseg, inverse);
+            auto steps = build_steps(p->sub, p->bs_a, p->bs_conv);
+            rc = run_steps(steps, st);
+            if (rc == PBH_OK) {
+                hipLaunchKernelGGL(k_seg_post, dim3(grid(n * nseg * S)), dim3(256), 0, st, (const cf*)p->bs_conv,
+                                   (const cf*)p->bs_b, dout, n, (int)S, inner, nseg, inverse, (real)(1.0 / (double)n));
+                if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "stft ring kernels failed to launch");
+            }
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e2;
+    }
+    if (stg_in) hipFree(stg_in);
+    if (stg_out) hipFree(stg_out);
+    if (rc != PBH_OK) return rc;
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_stft: ") + hipGetErrorString(e));
     return PBH_OK;
 }
 

@@ -22,6 +22,7 @@
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
     int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
     int P##fft_c2c(int, void*, int, const void*, void*, int64_t, int64_t, int, int, int);                       \
+    int P##stft(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                    \
     int P##plan_profile(P##plan*, const void*, void*, int, float*, int*, const char**);                         \
     }
 PBH_DECLARE_IMPL(pbh32_)
@@ -122,6 +123,12 @@ int pbh_fft_c2c(int device, void* stream, int dtype, const void* in, void* out, 
                 int il, int ol) {
     if (dtype == PBH_C128) return done(PBH_C128, pbh64_fft_c2c(device, stream, dtype, in, out, n, batch, inverse, il, ol));
     if (dtype == PBH_C64) return done(PBH_C64, pbh32_fft_c2c(device, stream, dtype, in, out, n, batch, inverse, il, ol));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_stft(int device, void* stream, int dtype, const void* in, void* out, int64_t nseg, int nperseg, int nchan,
+             int inner, int inverse, int il, int ol) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_stft(device, stream, dtype, in, out, nseg, nperseg, nchan, inner, inverse, il, ol));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_stft(device, stream, dtype, in, out, nseg, nperseg, nchan, inner, inverse, il, ol));
     return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
 }
 int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* ms, int* nk, const char** names) {

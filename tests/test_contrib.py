@@ -1,0 +1,91 @@
+"""contrib.stft / istft.  CPU: the oracle restatement against the reference's
+own known answers (tests/test_contrib.py:22-51).  GPU: the HIP path against the oracle and the same
+reference tests, for power-of-two and arbitrary nperseg, both dtypes, host and device data."""
+
+import numpy as np
+import pytest
+
+import pulsarbat_amd as pb
+from pulsarbat_amd import units as u
+from oracle import dedisp_oracle as orc
+
+
+def test_oracle_single_tone():
+    """reference tests/test_contrib.py:41-51."""
+    x = np.exp(2j * np.pi * np.arange(1024) * 0.25)[:, None]
+    for n in [32, 64, 512, 1024]:
+        y = orc.stft(x, n)
+        a = np.zeros_like(y)
+        a[:, 3 * n // 4] = 1.0
+        assert np.allclose(a, y)
+
+
+@pytest.mark.parametrize("shape", [(4224, 4, 2), (4233, 3, 2)])
+def test_oracle_reversibility(shape):
+    """reference tests/test_contrib.py:23-39."""
+    x = np.exp(1j * np.random.default_rng(0).uniform(-np.pi, np.pi, shape))
+    for n in [33, 32, shape[0]]:
+        y = orc.istft(orc.stft(x, n), n)
+        assert np.allclose(x[: len(y)], y)
+
+
+def assert_equal_radiosignals(x, y):
+    assert np.allclose(np.array(x), np.array(y), atol=2e-6), f"{x.shape}, {y.shape}"
+    assert x.start_time.isclose(y.start_time)
+    assert u.isclose(x.sample_rate, y.sample_rate)
+    assert np.allclose(x.channel_freqs.to_value(u.Hz), y.channel_freqs.to_value(u.Hz))
+
+
+@pytest.mark.gpu
+class TestSTFT:
+    @pytest.mark.parametrize("shape", [(4224, 4, 2), (4233, 3, 2)])
+    @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+    @pytest.mark.parametrize("device", [False, True])
+    def test_reversibility(self, shape, dtype, device):
+        """reference tests/test_contrib.py:23-39 (dask replaced by device-resident data)."""
+        kw = {"sample_rate": 4 * u.MHz, "center_freq": 400 * u.MHz, "pol_type": "linear",
+              "start_time": pb.Time.now()}
+        x = np.exp(1j * np.random.default_rng(1).uniform(-np.pi, +np.pi, shape)).astype(dtype)
+        z = pb.DualPolarizationSignal(x, **kw)
+        zz = z.to_device() if device else z
+        for n in [33, 32, shape[0]]:
+            s = pb.contrib.stft(zz, nperseg=n)
+            assert s.shape == (shape[0] // n, shape[1] * n, shape[2]) and s.dtype == dtype
+            want = orc.stft(x, n)
+            tol = 3e-6 if dtype == np.complex64 else 1e-12
+            assert np.abs(np.asarray(s) - want).max() < tol * max(1.0, np.abs(want).max())
+            y = pb.contrib.istft(s, nperseg=n)
+            assert isinstance(y, type(z))
+            assert isinstance(y.data, type(zz.data))
+            assert_equal_radiosignals(z[: len(y)], y)
+
+    def test_single_tone(self):
+        """reference tests/test_contrib.py:41-51."""
+        x = np.exp(2j * np.pi * np.arange(1024) * 0.25)[:, None].astype(np.complex64)
+        z = pb.BasebandSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+        for n in [32, 64, 512, 1024]:
+            y = pb.contrib.stft(z, nperseg=n)
+            a = np.zeros_like(y.data)
+            a[:, 3 * n // 4] = 1.0
+            assert np.allclose(a, y.data, atol=2e-6)
+
+    def test_signal_bookkeeping_and_errors(self):
+        x = np.ones((1024, 2), np.complex64)
+        z = pb.BasebandSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+        y = pb.contrib.stft(z, nperseg=256)
+        assert y.sample_rate.to_value(u.Hz) == pytest.approx(1e6 / 256) and y.freq_align == "bottom"
+        assert pb.contrib.stft(z, nperseg=5).freq_align == "center"
+        assert pb.contrib.stft(z, window="hann") is NotImplemented
+        assert pb.contrib.istft(z, noverlap=3) is NotImplemented
+        with pytest.raises(ValueError):
+            pb.contrib.stft(pb.Signal(x, sample_rate=1 * u.MHz))
+
+    @pytest.mark.parametrize("n", [64, 4096, 16384, 100, 3000])
+    def test_large_blocks(self, n):
+        x = orc.synthetic_block((n * 7 + 3, 8, 2), n)
+        z = pb.BasebandSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+        s = pb.contrib.stft(z.to_device(), nperseg=n)
+        want = orc.stft(x, n)
+        assert np.linalg.norm(np.asarray(s) - want) / np.linalg.norm(want) < 3e-6
+        y = pb.contrib.istft(s, nperseg=n)
+        assert np.linalg.norm(np.asarray(y) - x[: len(y)]) / np.linalg.norm(x) < 3e-6
