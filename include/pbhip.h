@@ -113,6 +113,19 @@ int pbh_chirp_download(pbh_plan* plan, void* chirp_c64, int loc);
 int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t nsample, double dt_s,
                        double center_freq_hz, double ref_freq_hz, void* chirp_c64, int loc);
 
+/* Transfer functions of the sibling transforms that share the FFT * H * IFFT skeleton
+ * (pulsarbat/transforms/transforms.py): mode 0 = time_shift's phase ramp complex64(exp(-2 pi i shift_c f_k)),
+ * f = fftfreq(nsample, 1) (transforms.py:266-270), arg = shift in samples per channel; mode 1 = freq_shift's
+ * out-of-band mask in fftshifted order (transforms.py:350-359), arg = ft * nsample per channel.  Then
+ * pbh_dedisperse runs ifft(fft(x) * H) with the plan's crop.  Power-of-two nsample only.                  */
+int pbh_chirp_special(pbh_plan* plan, const double* arg /* [nchan] */, int mode);
+/* freq_shift's mixer (transforms.py:346): out[n, s] = in[n, s] * exp(2 pi i ft[s] n); device arrays (n, s). */
+int pbh_mix(int device, void* hip_stream, int dtype, const void* in_dev, void* out_dev, int64_t nsample,
+            int nseries, const double* ft /* [nseries], host */);
+/* time_shift's zero fill of wrapped samples (transforms.py:274-286) on a device (nsample, nseries) array.  */
+int pbh_zero_edges(int device, void* hip_stream, int dtype, void* data_dev, int64_t nsample, int nseries,
+                   const double* shift /* [nseries], host */);
+
 /* ---- the hot path ----------------------------------------------------------------------------- */
 /* Replaces  x = ifft(fft(z.data, axis=0) * chirp, axis=0)[start:stop]  (dedispersion.py:125-133).
  * in : (nsample, nchan, npol) c64;  out: (crop_stop-crop_start, nchan, npol) c64.                   */

@@ -219,3 +219,51 @@ def istft(y, nperseg):
     x = scipy.fft.ifft(x, axis=1, n=n)
     x = x[:, :n]
     return x.reshape((-1,) + x.shape[2:])
+
+
+def time_shift(x, shift, crop=False):
+    """pulsarbat/transforms/transforms.py:248-293 (time_shift) on the data array.  ``shift`` (samples)
+    broadcasts over the sample shape; returns (shifted, start, stop)."""
+    shift = np.array(shift, dtype=np.float64)
+    if shift.ndim > 0:
+        shift = shift[(slice(None),) * shift.ndim + (None,) * (x.ndim - shift.ndim - 1)]
+    f = np.fft.fftfreq(len(x), 1)[tuple(slice(None) if j == 0 else None for j in range(x.ndim))]
+    ph = np.exp(-2j * np.pi * shift * f).astype(np.complex64)
+    shifted = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * ph, axis=0)
+    shifted = shifted if np.iscomplexobj(x) else shifted.real
+    shifted = np.array(shifted)
+    start, stop = 0, 0
+    full = np.broadcast_to(shift, x.shape[1:]) if x.ndim > 1 else shift.reshape(())
+    it = np.nditer(full, flags=["multi_index"])
+    for a in it:
+        if a < 0:
+            a = int(np.floor(a))
+            shifted[(np.s_[a:],) + it.multi_index] = 0
+            stop = min(stop, a)
+        else:
+            a = int(np.ceil(a))
+            shifted[(np.s_[:a],) + it.multi_index] = 0
+            start = max(start, a)
+    if crop:
+        shifted = shifted[start:len(shifted) + stop]
+    return shifted, start, stop
+
+
+def freq_shift(x, ft):
+    """pulsarbat/transforms/transforms.py:337-361 (freq_shift) on the data array; ``ft`` = shift * dt
+    (cycles per sample), broadcasting over the sample shape."""
+    ft = np.array(ft, dtype=np.float64)
+    if ft.ndim == 0:
+        ft = ft[None]
+    ft = ft[(slice(None),) * ft.ndim + (None,) * (x.ndim - ft.ndim - 1)]
+    n = np.arange(len(x))[tuple(slice(None) if j == 0 else None for j in range(x.ndim))]
+    ph = np.exp(2j * np.pi * ft * n).astype(x.dtype)
+    X = np.fft.fftshift(scipy.fft.fft(x * ph, axis=0), axes=(0,))
+    full = np.broadcast_to(ft * len(X), X.shape[1:])
+    it = np.nditer(full, flags=["multi_index"])
+    for a in it:
+        if a < 0:
+            X[(np.s_[int(np.floor(a)):],) + it.multi_index] = 0
+        else:
+            X[(np.s_[:int(np.ceil(a))],) + it.multi_index] = 0
+    return scipy.fft.ifft(np.fft.ifftshift(X, axes=(0,)), axis=0)

@@ -62,6 +62,10 @@ SIGNATURES = {
     "pbh_chirp_generate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double]),
     "pbh_chirp_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "pbh_chirp_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pbh_chirp_special": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "pbh_mix": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                          C.POINTER(C.c_double)]),
+    "pbh_zero_edges": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -204,6 +208,14 @@ class Plan:
         _check(lib().pbh_chirp_generate(self._h, float(coeff_hz), float(dt_s),
                                         freqs.ctypes.data_as(C.POINTER(C.c_double)), float(ref_freq_hz)))
 
+    def chirp_special(self, arg, mode):
+        """H = time_shift phase ramp (mode 0, arg = shifts in samples) or freq_shift mask (mode 1, arg = ft*N)."""
+        self._sync_stream()
+        a = np.ascontiguousarray(arg, dtype=np.float64)
+        if a.shape != (self.nchan,):
+            raise ValueError("arg must have shape (nchan,)")
+        _check(lib().pbh_chirp_special(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), int(mode)))
+
     def chirp_upload(self, chirp):
         self._sync_stream()
         if tuple(chirp.shape) != (self.nsample, self.nchan) or chirp.dtype != np.complex64:
@@ -334,6 +346,25 @@ def fft_c2c(x, inverse=False):
     pout, lout = _ptr_loc(out)
     _check(lib().pbh_fft_c2c(dev, stream, code, pin, pout, int(n), batch, int(bool(inverse)), lin, lout))
     return out
+
+
+def mix(x_dev, ft):
+    """In-place x[n, s] *= exp(2 pi i ft[s] n) on a device (n, s) array."""
+    a = np.ascontiguousarray(ft, dtype=np.float64)
+    n, s = x_dev.shape[0], int(np.prod(x_dev.shape[1:]))
+    p = C.c_void_p(x_dev.data_ptr())
+    _check(lib().pbh_mix(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype), p, p, int(n), s,
+                         a.ctypes.data_as(C.POINTER(C.c_double))))
+    return x_dev
+
+
+def zero_edges(x_dev, shift):
+    """time_shift's zero fill on a device (n, s) array (in place)."""
+    a = np.ascontiguousarray(shift, dtype=np.float64)
+    n, s = x_dev.shape[0], int(np.prod(x_dev.shape[1:]))
+    _check(lib().pbh_zero_edges(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype),
+                                C.c_void_p(x_dev.data_ptr()), int(n), s, a.ctypes.data_as(C.POINTER(C.c_double))))
+    return x_dev
 
 
 def stft(x, nperseg, inverse=False):

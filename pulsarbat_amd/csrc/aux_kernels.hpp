@@ -425,6 +425,72 @@ __global__ __launch_bounds__(256) void k_seg_post(const cf* __restrict__ conv, c
     }
 }
 
+// ---- time_shift / freq_shift (pulsarbat/transforms/transforms.py:211-361): same FFT * H * IFFT skeleton ----
+// H for time_shift: complex64(exp(-2 pi i shift_c f_k)), f_k = fftfreq(N, 1)[k] = bin/N   (transforms.py:270)
+// H for freq_shift: 0/1 band mask in fftshifted order (transforms.py:350-359): with a = ft*N,
+//   a < 0: zero shifted indices >= N + floor(a);  a >= 0: zero shifted indices < ceil(a);
+//   bin k sits at shifted index (k + N/2) % N.
+// Written in plan order like k_chirp (mode 0: phase ramp, 1: mask), times `scale`.
+__global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const double* __restrict__ arg, int mode) {
+    const int64_t total = p.N * p.nchan;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
+         d += (int64_t)gridDim.x * blockDim.x) {
+        const int chan = (int)(d / p.N);
+        const int64_t e = d - (int64_t)chan * p.N;
+        const int64_t k1 = e / p.N2, k2 = row_bin(e - k1 * p.N2, p.N2, p.perm_w);
+        const int64_t k = k1 + (int64_t)p.N1 * k2;
+        const double a = arg[chan];
+        if (mode == 0) {
+            const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;
+            const double phi = a * ((double)bin / (double)p.N);  // cycles
+            const double fr = phi - rint(phi);
+            double sn, cs;
+            sincospi(2.0 * fr, &sn, &cs);
+            p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
+        } else {
+            const int64_t i = (k + p.N / 2) % p.N;
+            bool zero;
+            if (a < 0) zero = i >= p.N + (int64_t)floor(a);
+            else zero = i < (int64_t)ceil(a);
+            p.out[d] = make_cf(zero ? (real)0 : p.scale, (real)0);
+        }
+    }
+}
+
+// out[n, s] = in[n, s] * exp(2 pi i ft[s] n), the phasor rounded to the data's precision (transforms.py:346)
+__global__ __launch_bounds__(256) void k_mix(const cf* __restrict__ in, cf* __restrict__ out,
+                                             const double* __restrict__ ft, int64_t N, int S) {
+    const int64_t total = N * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / S;
+        const int s = (int)(e - n * S);
+        const double phi = ft[s] * (double)n;
+        const double fr = phi - rint(phi);
+        double sn, cs;
+        sincospi(2.0 * fr, &sn, &cs);
+        out[e] = cmul(in[e], make_cf((real)cs, (real)sn));
+    }
+}
+
+// zero-fill of the wrapped-around samples of time_shift (transforms.py:274-286): series s with shift a:
+// a < 0: rows [N + floor(a), N);  a >= 0: rows [0, ceil(a)).  `data` is (N, S).
+__global__ __launch_bounds__(256) void k_zero_edges(cf* __restrict__ data, const double* __restrict__ shift,
+                                                    int64_t N, int S, int64_t maxrows) {
+    const int64_t total = maxrows * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = e / S;
+        const int s = (int)(e - j * S);
+        const double a = shift[s];
+        if (a < 0) {
+            const int64_t cnt = -(int64_t)floor(a);
+            if (j < cnt && j < N) data[(N - 1 - j) * S + s] = make_cf(0, 0);
+        } else {
+            const int64_t cnt = (int64_t)ceil(a);
+            if (j < cnt && j < N) data[j * S + s] = make_cf(0, 0);
+        }
+    }
+}
+
 #ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {

@@ -16,6 +16,9 @@
 #define pbh_chirp_upload PBH_FN(chirp_upload)
 #define pbh_chirp_download PBH_FN(chirp_download)
 #define pbh_chirp_function PBH_FN(chirp_function)
+#define pbh_chirp_special PBH_FN(chirp_special)
+#define pbh_mix PBH_FN(mix)
+#define pbh_zero_edges PBH_FN(zero_edges)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
@@ -686,6 +689,78 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
         HIPCHECK(hipMemcpyAsync(chirp_c64, dst, bytes, hipMemcpyDeviceToHost, p->stream));
         HIPCHECK(hipStreamSynchronize(p->stream));
     }
+    return PBH_OK;
+}
+
+// H = phase ramp (mode 0, arg = per-channel shift in samples) or band mask (mode 1, arg = ft*N)
+int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
+    if (!p || !arg) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (mode != 0 && mode != 1) return fail(PBH_ERR_INVALID, "bad mode");
+    if (p->bsL) return fail(PBH_ERR_UNSUPPORTED, "time/freq shift plans need a power-of-two nsample in this build");
+    HIPCHECK(hipSetDevice(p->device));
+    HIPCHECK(hipMemcpyAsync(p->chan_freq, arg, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
+    ChirpParams cp{p->chirp, p->chan_freq, 0.0, 0.0, 0.0, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
+    hipLaunchKernelGGL(k_chirp_special, dim3(2048), dim3(256), 0, p->stream, cp, (const double*)p->chan_freq, mode);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(p->stream));
+    p->has_chirp = true;
+    return PBH_OK;
+}
+
+static int with_device_doubles(const double* host, int n, hipStream_t st, double** dev) {
+    PBHCHECK(dev_alloc(nullptr, (void**)dev, sizeof(double) * (size_t)n));
+    hipError_t e = hipMemcpyAsync(*dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+        hipFree(*dev);
+        return fail(PBH_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    return PBH_OK;
+}
+
+// out[n, s] = in[n, s] * exp(2 pi i ft[s] n)  (device-resident (N, S) arrays; in may equal out)
+int pbh_mix(int device, void* hip_stream, int /*dtype*/, const void* in_dev, void* out_dev, int64_t nsample, int nseries,
+            const double* ft /*[nseries] host*/) {
+    if (!in_dev || !out_dev || !ft) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    double* d = nullptr;
+    PBHCHECK(with_device_doubles(ft, nseries, st, &d));
+    int64_t blocks = (nsample * nseries + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_mix, dim3((unsigned)blocks), dim3(256), 0, st, (const cf*)in_dev, (cf*)out_dev, (const double*)d,
+                       nsample, nseries);
+    hipError_t e = hipGetLastError();
+    hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_mix: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+int pbh_zero_edges(int device, void* hip_stream, int /*dtype*/, void* data_dev, int64_t nsample, int nseries,
+                   const double* shift /*[nseries] host*/) {
+    if (!data_dev || !shift) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int64_t maxrows = 0;
+    for (int i = 0; i < nseries; ++i) {
+        const double a = shift[i];
+        const int64_t c = a < 0 ? -(int64_t)floor(a) : (int64_t)ceil(a);
+        if (c > maxrows) maxrows = c;
+    }
+    if (maxrows > nsample) maxrows = nsample;
+    if (maxrows == 0) return PBH_OK;
+    double* d = nullptr;
+    PBHCHECK(with_device_doubles(shift, nseries, st, &d));
+    int64_t blocks = (maxrows * nseries + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_zero_edges, dim3((unsigned)blocks), dim3(256), 0, st, (cf*)data_dev, (const double*)d, nsample,
+                       nseries, maxrows);
+    hipError_t e = hipGetLastError();
+    hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_zero_edges: ") + hipGetErrorString(e));
     return PBH_OK;
 }
 

@@ -17,6 +17,9 @@
     int P##chirp_generate(P##plan*, double, double, const double*, double);                                     \
     int P##chirp_upload(P##plan*, const void*, int);                                                            \
     int P##chirp_download(P##plan*, void*, int);                                                                \
+    int P##chirp_special(P##plan*, const double*, int);                                                         \
+    int P##mix(int, void*, int, const void*, void*, int64_t, int, const double*);                               \
+    int P##zero_edges(int, void*, int, void*, int64_t, int, const double*);                                     \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
@@ -101,6 +104,17 @@ int pbh_chirp_generate(pbh_plan* p, double c, double dt, const double* f, double
 }
 int pbh_chirp_upload(pbh_plan* p, const void* c, int loc) { FORWARD(p, pbh32_chirp_upload(P32(p), c, loc), pbh64_chirp_upload(P64(p), c, loc)); }
 int pbh_chirp_download(pbh_plan* p, void* c, int loc) { FORWARD(p, pbh32_chirp_download(P32(p), c, loc), pbh64_chirp_download(P64(p), c, loc)); }
+int pbh_chirp_special(pbh_plan* p, const double* a, int m) { FORWARD(p, pbh32_chirp_special(P32(p), a, m), pbh64_chirp_special(P64(p), a, m)); }
+int pbh_mix(int device, void* stream, int dtype, const void* in, void* out, int64_t n, int ns, const double* ft) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_mix(device, stream, dtype, in, out, n, ns, ft));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_mix(device, stream, dtype, in, out, n, ns, ft));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_zero_edges(int device, void* stream, int dtype, void* data, int64_t n, int ns, const double* sh) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_zero_edges(device, stream, dtype, data, n, ns, sh));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_zero_edges(device, stream, dtype, data, n, ns, sh));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
 int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double dt, double fc, double fr, void* out, int loc) {
     return done(PBH_C64, pbh32_chirp_function(device, stream, coeff, n, dt, fc, fr, out, loc));
 }

@@ -1,6 +1,9 @@
-"""Transforms on the hot path (reference pulsarbat/transforms/__init__.py)."""
+"""Transforms on the hot path and its next rows (reference pulsarbat/transforms/__init__.py)."""
 
+from . import transforms
+from .transforms import *
 from . import dedispersion
 from .dedispersion import *
 
-__all__ = dedispersion.__all__.copy()
+__all__ = transforms.__all__.copy()
+__all__ += dedispersion.__all__

@@ -1,0 +1,120 @@
+"""``time_shift`` / ``freq_shift`` (reference pulsarbat/transforms/transforms.py:211-361; SURVEY.md 8f
+rank 2).  Same FFT * H * IFFT skeleton as coherent dedispersion -- H is a phase ramp (time_shift) or
+a band mask after a mixer (freq_shift) -- so both run on the plan pipeline of libpbhip.so with the
+transfer function generated on the device (``pbh_chirp_special``), plus two elementwise kernels
+(``pbh_mix``, ``pbh_zero_edges``).  Argument handling, broadcasting rules, zero fill, crop and
+``start_time`` bookkeeping follow the reference line by line.  Power-of-two lengths in this build.
+"""
+
+import math
+
+import numpy as np
+
+from .. import _hip
+from .. import units as u
+from ..core import BasebandSignal
+from ..device import DeviceArray
+
+__all__ = ["time_shift", "freq_shift"]
+
+
+def _per_series(arr, z):
+    """Broadcast ``arr`` (already given trailing length-1 axes) over ``z.sample_shape`` -> flat (S,)."""
+    try:
+        full = np.broadcast_to(arr, z.sample_shape)
+    except ValueError:
+        raise ValueError(f"shift of shape {np.shape(arr)} does not broadcast to the sample shape {z.sample_shape}")
+    return np.ascontiguousarray(full, dtype=np.float64).reshape(-1)
+
+
+def _to_device_complex(z):
+    """(DeviceArray (N, S) complex, was_device, was_real, original dtype)."""
+    data = z.data
+    on_dev = isinstance(data, DeviceArray)
+    dt = np.dtype(data.dtype)
+    real = dt.kind != "c"
+    cdt = np.complex64 if dt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.complex128
+    if on_dev:
+        d = data.contiguous()
+        if real or d.dtype != cdt:
+            d = d.astype(cdt)
+    else:
+        d = DeviceArray.from_host(np.ascontiguousarray(data).astype(cdt, copy=False))
+    return d, on_dev, real, dt
+
+
+def _from_device(y, on_dev, real, dt, shape):
+    if on_dev:
+        t = y.tensor.reshape(shape)
+        return DeviceArray(t.real.contiguous() if real else t)
+    a = y.get().reshape(shape)
+    return np.ascontiguousarray(a.real).astype(dt, copy=False) if real else a
+
+
+def time_shift(z, /, shift, crop=False):
+    """Shift signal data in time by a phase gradient in the frequency domain (transforms.py:211-293).
+
+    ``shift`` is in samples (number / array broadcasting over the sample shape) or a time Quantity.
+    Samples that wrapped around are zero-filled; ``crop=True`` removes them instead and advances
+    ``start_time`` by ``max(0, shift.max()) * dt``.
+    """
+    if hasattr(shift, "unit") and hasattr(shift, "to_value"):
+        shift = (shift * z.sample_rate).to_value(u.one)
+    shift = np.array(shift, dtype=np.float64)
+    if shift.ndim >= z.ndim:
+        raise ValueError(f"shift has too many dimensions. Expected <= {z.ndim - 1} dimensions, "
+                         f"got {shift.ndim} dimensions!")
+    if np.allclose(shift, 0):
+        return z
+    if shift.ndim > 0:
+        shift = shift[(slice(None),) * shift.ndim + (None,) * (z.ndim - shift.ndim - 1)]
+    sh = _per_series(shift, z)
+
+    start = max([0] + [int(math.ceil(a)) for a in sh if a >= 0])
+    stop = min([0] + [int(math.floor(a)) for a in sh if a < 0])
+    N = len(z)
+    x, on_dev, real, dt = _to_device_complex(z)
+    S = sh.size
+    lo, hi = (start, N + stop) if crop else (0, N)
+    with _hip.Plan(N, S, 1, lo, hi, device=x.device_index, dtype=x.dtype) as plan:
+        plan.chirp_special(sh, 0)
+        y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
+    y = DeviceArray(y.tensor.reshape(hi - lo if hi > lo else 0, S))
+    if not crop:
+        _hip.zero_edges(y, sh)
+    out = _from_device(y, on_dev, real, dt, (y.shape[0],) + tuple(z.sample_shape))
+    kw = {}
+    if crop and z.start_time is not None:
+        kw["start_time"] = z.start_time + start / z.sample_rate
+    return type(z).like(z, out, **kw)
+
+
+def freq_shift(z, /, shift):
+    """Shift a baseband signal in frequency by mixing with a sinusoid; the out-of-band part is zeroed
+    (transforms.py:296-361)."""
+    if not isinstance(z, BasebandSignal):
+        raise TypeError("Signal must be a BasebandSignal object.")
+    try:
+        hz = np.asarray(u.to_value(shift.to(u.Hz) if hasattr(shift, "to") else shift, u.Hz), dtype=np.float64)
+        if not hasattr(shift, "to"):
+            raise TypeError
+    except Exception:
+        raise ValueError("shift must be a Quantity with units of frequency.")
+    if hz.ndim == 0:
+        hz = hz[None]
+    if hz.ndim >= z.ndim:
+        raise ValueError(f"shift has too many dimensions. Expected <= {z.ndim - 1} dimensions, "
+                         f"got {hz.ndim} dimensions!")
+    hz = hz[(slice(None),) * hz.ndim + (None,) * (z.ndim - hz.ndim - 1)]
+    ft = _per_series(hz * u.to_value(z.dt, u.s), z)
+
+    N = len(z)
+    x, on_dev, real, dt = _to_device_complex(z)
+    S = ft.size
+    xm = DeviceArray(x.tensor.reshape(N, S).clone())  # the mixer works in place: keep the caller's data
+    _hip.mix(xm, ft)
+    with _hip.Plan(N, S, 1, 0, N, device=xm.device_index, dtype=xm.dtype) as plan:
+        plan.chirp_special(ft * N, 1)
+        y = plan.dedisperse(DeviceArray(xm.tensor.reshape(N, S, 1)))
+    out = _from_device(DeviceArray(y.tensor.reshape(N, S)), on_dev, False, dt, (N,) + tuple(z.sample_shape))
+    return type(z).like(z, out)
