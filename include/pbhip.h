@@ -126,6 +126,16 @@ int pbh_mix(int device, void* hip_stream, int dtype, const void* in_dev, void* o
 int pbh_zero_edges(int device, void* hip_stream, int dtype, void* data_dev, int64_t nsample, int nseries,
                    const double* shift /* [nseries], host */);
 
+/* DualPolarizationSignal.to_circular / to_linear (pulsarbat/core.py:882-928) on device (n, nchan, 2)
+ * data: npairs = n * nchan.  to_circular: L = (X - iY)/sqrt2, R = (X + iY)/sqrt2; else the inverse.       */
+int pbh_pol_basis(int device, void* hip_stream, int dtype, const void* in_dev, void* out_dev, int64_t npairs,
+                  int to_circular);
+/* incoherent_dedispersion's gather (pulsarbat/transforms/dedispersion.py:171): out[n, c, :] =
+ * in[n + delay[c], c, :] for n < nout, on device data of any dtype with unit_words 4-byte words per
+ * (sample, channel).  delay: host array of non-negative sample offsets.                                   */
+int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
+                   int unit_words, const int64_t* delay);
+
 /* ---- the hot path ----------------------------------------------------------------------------- */
 /* Replaces  x = ifft(fft(z.data, axis=0) * chirp, axis=0)[start:stop]  (dedispersion.py:125-133).
  * in : (nsample, nchan, npol) c64;  out: (crop_stop-crop_start, nchan, npol) c64.                   */

@@ -267,3 +267,17 @@ def freq_shift(x, ft):
         else:
             X[(np.s_[:int(np.ceil(a))],) + it.multi_index] = 0
     return scipy.fft.ifft(np.fft.ifftshift(X, axes=(0,)), axis=0)
+
+
+def incoherent_dedispersion(x, dm, sample_rate_hz, center_freq_hz, chan_bw_hz, freq_align="center",
+                            ref_freq_hz=None):
+    """pulsarbat/transforms/dedispersion.py:136-177 on the data array; returns (y, crop_before)."""
+    if ref_freq_hz is None:
+        ref_freq_hz = center_freq_hz
+    freqs = channel_freqs(center_freq_hz, chan_bw_hz, x.shape[1], freq_align)
+    delays = np.asarray(sample_delay(dm, freqs, ref_freq_hz, sample_rate_hz)).round().astype(np.int64)
+    crop_before = -min(0, delays[0], delays[-1])
+    delays = delays + crop_before
+    N = len(x) - max(delays)
+    y = np.stack([x[j:j + N, i] for i, j in enumerate(delays)], axis=1)
+    return y, int(crop_before)

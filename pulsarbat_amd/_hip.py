@@ -66,6 +66,9 @@ SIGNATURES = {
     "pbh_mix": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                           C.POINTER(C.c_double)]),
     "pbh_zero_edges": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
+    "pbh_pol_basis": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "pbh_incoherent": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int64)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -365,6 +368,32 @@ def zero_edges(x_dev, shift):
     _check(lib().pbh_zero_edges(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype),
                                 C.c_void_p(x_dev.data_ptr()), int(n), s, a.ctypes.data_as(C.POINTER(C.c_double))))
     return x_dev
+
+
+def pol_basis(x_dev, to_circular):
+    """to_circular / to_linear of a device (n, nchan, 2) complex array -> new DeviceArray."""
+    from .device import DeviceArray
+    x_dev = x_dev.contiguous()
+    out = DeviceArray.empty(x_dev.shape, x_dev.dtype, device=x_dev.device_index)
+    _check(lib().pbh_pol_basis(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype),
+                               C.c_void_p(x_dev.data_ptr()), C.c_void_p(out.data_ptr()), x_dev.size // 2,
+                               int(bool(to_circular))))
+    return out
+
+
+def incoherent(x_dev, delays, nout):
+    """out[n, c, ...] = x[n + delays[c], c, ...], n < nout, for a device array of any 4/8/16-byte dtype."""
+    from .device import DeviceArray
+    x_dev = x_dev.contiguous()
+    nchan = x_dev.shape[1]
+    inner = int(np.prod(x_dev.shape[2:])) if x_dev.ndim > 2 else 1
+    unit = inner * x_dev.dtype.itemsize // 4
+    d = np.ascontiguousarray(delays, dtype=np.int64)
+    out = DeviceArray.empty((int(nout),) + tuple(x_dev.shape[1:]), x_dev.dtype, device=x_dev.device_index)
+    _check(lib().pbh_incoherent(x_dev.device_index, _stream_ptr(x_dev.device_index), C.c_void_p(x_dev.data_ptr()),
+                                C.c_void_p(out.data_ptr() if nout > 0 else x_dev.data_ptr()), int(nout), int(nchan),
+                                int(unit), d.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
 
 
 def stft(x, nperseg, inverse=False):

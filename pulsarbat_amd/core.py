@@ -453,16 +453,24 @@ class DualPolarizationSignal(BasebandSignal):
         """core.py:882-904: X = (L + R)/sqrt2, Y = i(L - R)/sqrt2."""
         z = self.data
         if self.pol_type == "circular":
-            ax, L, R = self._pols()
-            z = np.stack([L + R, 1j * (L - R)], axis=ax) / np.sqrt(2)
+            if _is_device(z) and self.ndim == 3:
+                from . import _hip
+                z = _hip.pol_basis(z, to_circular=False)
+            else:
+                ax, L, R = self._pols()
+                z = np.stack([L + R, 1j * (L - R)], axis=ax) / np.sqrt(2)
         return type(self).like(self, z, pol_type="linear")
 
     def to_circular(self):
         """core.py:906-928: L = (X - iY)/sqrt2, R = (X + iY)/sqrt2."""
         z = self.data
         if self.pol_type == "linear":
-            ax, X, Y = self._pols()
-            z = np.stack([X - 1j * Y, X + 1j * Y], axis=ax) / np.sqrt(2)
+            if _is_device(z) and self.ndim == 3:
+                from . import _hip
+                z = _hip.pol_basis(z, to_circular=True)
+            else:
+                ax, X, Y = self._pols()
+                z = np.stack([X - 1j * Y, X + 1j * Y], axis=ax) / np.sqrt(2)
         return type(self).like(self, z, pol_type="circular")
 
     def to_stokes(self):

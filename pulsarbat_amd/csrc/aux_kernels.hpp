@@ -492,6 +492,44 @@ __global__ __launch_bounds__(256) void k_zero_edges(cf* __restrict__ data, const
 }
 
 #ifndef PBH_F64
+// ---- incoherent dedispersion (pulsarbat/transforms/dedispersion.py:136-177): per-channel integer shift ----
+// out[n, c, :] = in[n + delay[c], c, :], n < nout.  A pure gather: rows of `unit` 4-byte words per
+// (sample, channel) (float32 Stokes: inner words; complex64: 2*inner; float64: 2*inner; ...).
+__global__ __launch_bounds__(256) void k_incoherent(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                    const int64_t* __restrict__ delay, int64_t nout, int nchan,
+                                                    int unit) {
+    const int64_t row = (int64_t)nchan * unit;  // words per time sample
+    const int64_t total = nout * row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / row;
+        const int r = (int)(e - n * row);
+        const int c = r / unit;
+        out[e] = in[(n + delay[c]) * row + r];
+    }
+}
+#endif  // !PBH_F64
+
+// ---- polarisation basis change (pulsarbat/core.py:882-928) on (n, nchan, 2) data --------------------------------
+// to_circular: L = (X - iY)/sqrt2, R = (X + iY)/sqrt2;   to_linear: X = (L + R)/sqrt2, Y = i(L - R)/sqrt2
+__global__ __launch_bounds__(256) void k_pol_basis(const cf* __restrict__ in, cf* __restrict__ out, int64_t npairs,
+                                                   int to_circular) {
+    const real h = RC(0.70710678118654752);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < npairs; e += (int64_t)gridDim.x * blockDim.x) {
+        const cf a = in[2 * e], b = in[2 * e + 1];
+        cf p, q;
+        if (to_circular) {  // a = X, b = Y:  iY = (-b.y, b.x)
+            p = make_cf((a.x + b.y) * h, (a.y - b.x) * h);
+            q = make_cf((a.x - b.y) * h, (a.y + b.x) * h);
+        } else {            // a = L, b = R:  i(L - R) = (-(a.y - b.y), a.x - b.x)
+            p = make_cf((a.x + b.x) * h, (a.y + b.y) * h);
+            q = make_cf(-(a.y - b.y) * h, (a.x - b.x) * h);
+        }
+        out[2 * e] = p;
+        out[2 * e + 1] = q;
+    }
+}
+
+#ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -19,6 +19,8 @@
 #define pbh_chirp_special PBH_FN(chirp_special)
 #define pbh_mix PBH_FN(mix)
 #define pbh_zero_edges PBH_FN(zero_edges)
+#define pbh_pol_basis PBH_FN(pol_basis)
+#define pbh_incoherent PBH_FN(incoherent)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
@@ -763,6 +765,46 @@ int pbh_zero_edges(int device, void* hip_stream, int /*dtype*/, void* data_dev, 
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_zero_edges: ") + hipGetErrorString(e));
     return PBH_OK;
 }
+
+// to_circular / to_linear (core.py:882-928) on device (n, nchan, 2) data; in may equal out
+int pbh_pol_basis(int device, void* hip_stream, int /*dtype*/, const void* in_dev, void* out_dev, int64_t npairs,
+                  int to_circular) {
+    if (!in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (npairs <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    HIPCHECK(hipSetDevice(device));
+    int64_t blocks = (npairs + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_pol_basis, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, (const cf*)in_dev,
+                       (cf*)out_dev, npairs, to_circular);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+#ifndef PBH_F64
+// incoherent dedispersion gather on device data of any dtype: `unit` 4-byte words per (sample, channel)
+int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
+                   int unit_words, const int64_t* delay /*[nchan] host, >= 0*/) {
+    if (!in_dev || !out_dev || !delay) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nout < 0 || nchan <= 0 || unit_words <= 0) return fail(PBH_ERR_INVALID, "bad size");
+    if (nout == 0) return PBH_OK;
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int64_t* d = nullptr;
+    PBHCHECK(dev_alloc(nullptr, (void**)&d, sizeof(int64_t) * (size_t)nchan));
+    hipError_t e = hipMemcpyAsync(d, delay, sizeof(int64_t) * (size_t)nchan, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        int64_t blocks = (nout * nchan * unit_words + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(k_incoherent, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)in_dev,
+                           (uint32_t*)out_dev, (const int64_t*)d, nout, nchan, unit_words);
+        e = hipGetLastError();
+    }
+    hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_incoherent: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+#endif
 
 #ifndef PBH_F64
 int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t nsample, double dt_s,

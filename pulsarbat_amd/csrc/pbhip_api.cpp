@@ -20,6 +20,7 @@
     int P##chirp_special(P##plan*, const double*, int);                                                         \
     int P##mix(int, void*, int, const void*, void*, int64_t, int, const double*);                               \
     int P##zero_edges(int, void*, int, void*, int64_t, int, const double*);                                     \
+    int P##pol_basis(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
@@ -35,6 +36,7 @@ int pbh32_device_count(void);
 const char* pbh32_version(void);
 int pbh32_chirp_function(int, void*, double, int64_t, double, double, double, void*, int);
 int pbh32_copy_bench(int, int64_t, int, float*);
+int pbh32_incoherent(int, void*, const void*, void*, int64_t, int, int, const int64_t*);
 }
 
 struct pbh_plan {
@@ -114,6 +116,14 @@ int pbh_zero_edges(int device, void* stream, int dtype, void* data, int64_t n, i
     if (dtype == PBH_C128) return done(PBH_C128, pbh64_zero_edges(device, stream, dtype, data, n, ns, sh));
     if (dtype == PBH_C64) return done(PBH_C64, pbh32_zero_edges(device, stream, dtype, data, n, ns, sh));
     return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_pol_basis(int device, void* stream, int dtype, const void* in, void* out, int64_t np, int tc) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_pol_basis(device, stream, dtype, in, out, np, tc));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_pol_basis(device, stream, dtype, in, out, np, tc));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_incoherent(int device, void* stream, const void* in, void* out, int64_t nout, int nchan, int unit, const int64_t* d) {
+    return done(PBH_C64, pbh32_incoherent(device, stream, in, out, nout, nchan, unit, d));
 }
 int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double dt, double fc, double fr, void* out, int loc) {
     return done(PBH_C64, pbh32_chirp_function(device, stream, coeff, n, dt, fc, fr, out, loc));

@@ -16,7 +16,7 @@ import numpy as np
 
 from .. import _hip
 from .. import units as u
-from ..core import BasebandSignal
+from ..core import BasebandSignal, RadioSignal
 from ..device import DeviceArray
 
 __all__ = [
@@ -25,6 +25,7 @@ __all__ = [
     "coherent_dedispersion",
     "dedisperse_detect",
     "coherent_dedispersion_stream",
+    "incoherent_dedispersion",
 ]
 
 _DM_UNIT = u.pc / u.cm ** 3
@@ -68,7 +69,8 @@ class DispersionMeasure(u.Quantity):
 
     def sample_delay(self, f, ref_freq, sample_rate):
         """time_delay * sample_rate as plain floats (dedispersion.py:38-42)."""
-        return self.time_delay(f, ref_freq).to_value(u.s) * _hz(sample_rate)
+        # numpy scalar / array as in the reference (callers use .round(): tests/test_dedispersion.py:187)
+        return np.asarray(self.time_delay(f, ref_freq).to_value(u.s) * _hz(sample_rate))[()]
 
     def chirp_function(self, N, dt, center_freq, ref_freq, use_dask=False, *, device=None):
         """Transfer function of one channel, complex64 ``(N,)`` (dedispersion.py:44-57).
@@ -241,3 +243,28 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
     y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
     return type(z).like(z, y, **_advance(z, start)), ms
+
+
+def incoherent_dedispersion(z, DM, /, *, ref_freq=None):
+    """Incoherently dedisperse a signal: every channel is shifted by its dispersion delay rounded to
+    a whole sample, and the result is cropped to the samples all channels cover
+    (reference dedispersion.py:136-177).  Device-resident data is gathered by a HIP kernel
+    (``pbh_incoherent``); host data keeps the reference's numpy slicing (it is a pure copy).
+    """
+    if not isinstance(z, RadioSignal):
+        raise TypeError("Signal must be a RadioSignal object.")
+    if ref_freq is None:
+        ref_freq = z.center_freq
+    delays = np.asarray(DM.sample_delay(z.channel_freqs, ref_freq, z.sample_rate))
+    delays = delays.round().astype(np.int64)
+    crop_before = -min(0, delays[0], delays[-1])
+    delays = delays + crop_before
+    N = len(z) - max(delays)
+    if isinstance(z.data, DeviceArray):
+        x = _hip.incoherent(z.data, delays, max(N, 0))
+    else:
+        x = np.stack([z.data[j:j + N, i] for i, j in enumerate(delays)], axis=1)
+    new_start = z.start_time
+    if crop_before and z.start_time is not None:
+        new_start = new_start + crop_before * z.dt
+    return type(z).like(z, x, start_time=new_start)

@@ -1,0 +1,74 @@
+"""incoherent dedispersion and polarisation-basis changes on device data."""
+
+import numpy as np
+import pytest
+
+import pulsarbat_amd as pb
+from pulsarbat_amd import units as u
+from oracle import dedisp_oracle as orc
+
+
+def test_oracle_incoherent_length():
+    """reference tests/test_dedispersion.py:167-189 (length check) on the oracle restatement."""
+    shape, sr, ref, bw = (8192, 32, 4), 1e3, 1e9, 8e6
+    x = np.random.default_rng(0).standard_normal(shape)
+    for dm in (50.0, 100.0, 200.0):
+        y, _ = orc.incoherent_dedispersion(x, dm, sr, ref, bw)
+        f = orc.channel_freqs(ref, bw, 32)
+        top = round(float(orc.sample_delay(dm, ref, f[-1], sr)))
+        bot = round(float(orc.sample_delay(dm, f[0], ref, sr)))
+        assert len(x) - len(y) == int(top + bot)
+
+
+@pytest.mark.parametrize("dm", [50.0, 100.0, 200.0])
+@pytest.mark.parametrize("device", [False, pytest.param(True, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_incoherent_dedispersion(dm, device, dtype):
+    """reference tests/test_dedispersion.py:167-189 plus element-wise parity with the oracle."""
+    SR, ref_freq, shape = 1 * u.kHz, 1 * u.GHz, (8192, 32, 4)
+    t0 = pb.Time(56000.0, format="mjd")
+    DM = pb.DispersionMeasure(dm)
+    x = np.random.default_rng(1).standard_normal(shape).astype(dtype)
+    z1 = pb.FullStokesSignal(x, sample_rate=SR, start_time=t0, center_freq=ref_freq, chan_bw=8 * u.MHz)
+    with pytest.raises(TypeError):
+        pb.incoherent_dedispersion(pb.Signal(x, sample_rate=SR), DM)
+    z2 = pb.incoherent_dedispersion(z1.to_device() if device else z1, DM)
+    delay_top = DM.sample_delay(ref_freq, z1.channel_freqs[-1], SR).round()
+    delay_bot = DM.sample_delay(z1.channel_freqs[0], ref_freq, SR).round()
+    assert len(z1) - len(z2) == int(delay_top + delay_bot)
+    want, crop_before = orc.incoherent_dedispersion(x, dm, 1e3, 1e9, 8e6)
+    assert z2.dtype == dtype and type(z2) is type(z1)
+    assert np.array_equal(np.asarray(z2), want)                     # a gather: bit exact
+    assert abs((z2.start_time - t0).to_value(u.s) - crop_before / 1e3) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_incoherent_complex_device(dtype):
+    x = (np.random.default_rng(2).standard_normal((4096, 16, 2)) * (1 + 1j)).astype(dtype)
+    z = pb.DualPolarizationSignal(x, sample_rate=1 * u.kHz, center_freq=1 * u.GHz, pol_type="linear").to_device()
+    y = pb.incoherent_dedispersion(z, pb.DM(30.0))
+    want, _ = orc.incoherent_dedispersion(x, 30.0, 1e3, 1e9, 1e3)
+    assert isinstance(y.data, pb.DeviceArray) and np.array_equal(np.asarray(y), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pol_type", ["linear", "circular"])
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_pol_reversibility_device(pol_type, dtype):
+    """reference tests/test_polarization.py:10-31 on device-resident data."""
+    sig = np.exp(1j * np.random.default_rng(3).uniform(-np.pi, np.pi, (4096, 16, 2))).astype(dtype)
+    z = pb.DualPolarizationSignal(sig, pol_type=pol_type, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+    zd = z.to_device()
+    if pol_type == "linear":
+        x, y, mid, host_mid = zd.to_linear(), zd.to_circular().to_linear(), zd.to_circular(), z.to_circular()
+    else:
+        x, y, mid, host_mid = zd.to_circular(), zd.to_linear().to_circular(), zd.to_linear(), z.to_linear()
+    tol = 1e-6 if dtype == np.complex64 else 1e-13
+    assert np.allclose(np.asarray(mid), np.asarray(host_mid), atol=tol)
+    for a in (x, y):
+        assert isinstance(a.data, pb.DeviceArray) and a.pol_type == pol_type
+        assert np.allclose(np.array(z), np.array(a), atol=tol)
+    # Stokes from either basis agree (reference tests/test_polarization.py:50-60)
+    s1, s2 = zd.to_linear().to_stokes(), zd.to_circular().to_stokes()
+    assert np.allclose(np.asarray(s1), np.asarray(s2), atol=10 * tol)
