@@ -117,7 +117,8 @@ int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t ns
  * (pulsarbat/transforms/transforms.py): mode 0 = time_shift's phase ramp complex64(exp(-2 pi i shift_c f_k)),
  * f = fftfreq(nsample, 1) (transforms.py:266-270), arg = shift in samples per channel; mode 1 = freq_shift's
  * out-of-band mask in fftshifted order (transforms.py:350-359), arg = ft * nsample per channel.  Then
- * pbh_dedisperse runs ifft(fft(x) * H) with the plan's crop.  Power-of-two nsample only.                  */
+ * mode 2 = real_to_complex's analytic-signal weights (pulsarbat/utils.py:52-57), arg ignored.  Then
+ * pbh_dedisperse runs ifft(fft(x) * H) with the plan's crop.                                              */
 int pbh_chirp_special(pbh_plan* plan, const double* arg /* [nchan] */, int mode);
 /* freq_shift's mixer (transforms.py:346): out[n, s] = in[n, s] * exp(2 pi i ft[s] n); device arrays (n, s). */
 int pbh_mix(int device, void* hip_stream, int dtype, const void* in_dev, void* out_dev, int64_t nsample,
@@ -126,6 +127,9 @@ int pbh_mix(int device, void* hip_stream, int dtype, const void* in_dev, void* o
 int pbh_zero_edges(int device, void* hip_stream, int dtype, void* data_dev, int64_t nsample, int nseries,
                    const double* shift /* [nseries], host */);
 
+/* real_to_complex's tail (pulsarbat/utils.py:59-65: * exp(-i pi/2 n), then [::2]): out[m, s] = (-1)^m in[2m, s]. */
+int pbh_decimate2(int device, void* hip_stream, int dtype, const void* in_dev, void* out_dev, int64_t nout,
+                  int nseries);
 /* DualPolarizationSignal.to_circular / to_linear (pulsarbat/core.py:882-928) on device (n, nchan, 2)
  * data: npairs = n * nchan.  to_circular: L = (X - iY)/sqrt2, R = (X + iY)/sqrt2; else the inverse.       */
 int pbh_pol_basis(int device, void* hip_stream, int dtype, const void* in_dev, void* out_dev, int64_t npairs,

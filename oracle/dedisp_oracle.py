@@ -281,3 +281,26 @@ def incoherent_dedispersion(x, dm, sample_rate_hz, center_freq_hz, chan_bw_hz, f
     N = len(x) - max(delays)
     y = np.stack([x[j:j + N, i] for i, j in enumerate(delays)], axis=1)
     return y, int(crop_before)
+
+
+def real_to_complex(z, axis=0):
+    """pulsarbat/utils.py:38-65 (real_to_complex)."""
+    z = np.asarray(z)
+    if np.iscomplexobj(z):
+        raise ValueError("Input must be real-valued.")
+    out_dtype = np.complex64 if z.dtype == np.float32 else np.complex128
+    N = z.shape[axis]
+    if N == 0:
+        return z.astype(out_dtype)
+    ind = [np.newaxis] * z.ndim
+    ind[axis] = slice(None)
+    h = np.zeros(N, dtype=out_dtype)
+    h[0] = 1
+    h[1:N // 2] = 2
+    if N > 1:
+        h[N // 2] = 2 if N % 2 else 1
+    z = scipy.fft.ifft(scipy.fft.fft(z, axis=axis) * h[tuple(ind)], axis=axis)
+    z *= np.exp(-1j * np.pi / 2 * np.arange(N))[tuple(ind)]
+    dec = [slice(None)] * z.ndim
+    dec[axis] = slice(None, None, 2)
+    return z[tuple(dec)].astype(out_dtype)

@@ -18,7 +18,8 @@ from . import transforms
 from .transforms import *
 from . import fft
 from . import contrib
+from . import utils
 
-__all__ = ["fft", "contrib", "units", "Time", "DeviceArray", "InvalidSignalError"]
+__all__ = ["fft", "contrib", "utils", "units", "Time", "DeviceArray", "InvalidSignalError"]
 __all__.extend(core.__all__)
 __all__.extend(transforms.__all__)

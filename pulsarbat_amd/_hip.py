@@ -66,6 +66,7 @@ SIGNATURES = {
     "pbh_mix": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                           C.POINTER(C.c_double)]),
     "pbh_zero_edges": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
+    "pbh_decimate2": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pbh_pol_basis": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pbh_incoherent": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.POINTER(C.c_int64)]),
@@ -368,6 +369,17 @@ def zero_edges(x_dev, shift):
     _check(lib().pbh_zero_edges(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype),
                                 C.c_void_p(x_dev.data_ptr()), int(n), s, a.ctypes.data_as(C.POINTER(C.c_double))))
     return x_dev
+
+
+def decimate2(y_dev):
+    """out[m, s] = (-1)^m y[2m, s] for a device (n, s) complex array."""
+    from .device import DeviceArray
+    n, s = y_dev.shape[0], int(np.prod(y_dev.shape[1:]))
+    nout = (n + 1) // 2
+    out = DeviceArray.empty((nout,) + tuple(y_dev.shape[1:]), y_dev.dtype, device=y_dev.device_index)
+    _check(lib().pbh_decimate2(y_dev.device_index, _stream_ptr(y_dev.device_index), _dtype_code(y_dev.dtype),
+                               C.c_void_p(y_dev.data_ptr()), C.c_void_p(out.data_ptr()), int(nout), s))
+    return out
 
 
 def pol_basis(x_dev, to_circular):

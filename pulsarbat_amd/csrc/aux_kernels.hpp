@@ -447,12 +447,20 @@ __global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const doub
             double sn, cs;
             sincospi(2.0 * fr, &sn, &cs);
             p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
-        } else {
+        } else if (mode == 1) {
             const int64_t i = (k + p.N / 2) % p.N;
             bool zero;
             if (a < 0) zero = i >= p.N + (int64_t)floor(a);
             else zero = i < (int64_t)ceil(a);
             p.out[d] = make_cf(zero ? (real)0 : p.scale, (real)0);
+        } else {
+            // mode 2: analytic-signal weights of real_to_complex (pulsarbat/utils.py:52-57):
+            // h[0] = 1, h[1 : N/2] = 2, h[N/2] = 2 if N odd else 1, 0 above
+            real hv = 0;
+            if (k == 0) hv = 1;
+            else if (k < p.N / 2) hv = 2;
+            else if (k == p.N / 2) hv = (p.N & 1) ? 2 : 1;
+            p.out[d] = make_cf(hv * p.scale, (real)0);
         }
     }
 }
@@ -469,6 +477,16 @@ __global__ __launch_bounds__(256) void k_mix(const cf* __restrict__ in, cf* __re
         double sn, cs;
         sincospi(2.0 * fr, &sn, &cs);
         out[e] = cmul(in[e], make_cf((real)cs, (real)sn));
+    }
+}
+
+// real_to_complex tail (pulsarbat/utils.py:59-65): z *= exp(-i pi/2 n), then z[::2]  ==>  out[m] = (-1)^m y[2m]
+__global__ __launch_bounds__(256) void k_decimate2(const cf* __restrict__ y, cf* __restrict__ out, int64_t nout, int S) {
+    const int64_t total = nout * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / S;
+        const cf v = y[(2 * m) * S + (e - m * S)];
+        out[e] = (m & 1) ? make_cf(-v.x, -v.y) : v;
     }
 }
 

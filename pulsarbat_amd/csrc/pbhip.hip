@@ -20,6 +20,7 @@
 #define pbh_mix PBH_FN(mix)
 #define pbh_zero_edges PBH_FN(zero_edges)
 #define pbh_pol_basis PBH_FN(pol_basis)
+#define pbh_decimate2 PBH_FN(decimate2)
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
@@ -697,8 +698,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
 // H = phase ramp (mode 0, arg = per-channel shift in samples) or band mask (mode 1, arg = ft*N)
 int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     if (!p || !arg) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (mode != 0 && mode != 1) return fail(PBH_ERR_INVALID, "bad mode");
-    if (p->bsL) return fail(PBH_ERR_UNSUPPORTED, "time/freq shift plans need a power-of-two nsample in this build");
+    if (mode < 0 || mode > 2) return fail(PBH_ERR_INVALID, "bad mode");
     HIPCHECK(hipSetDevice(p->device));
     HIPCHECK(hipMemcpyAsync(p->chan_freq, arg, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, 0.0, 0.0, 0.0, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
@@ -763,6 +763,20 @@ int pbh_zero_edges(int device, void* hip_stream, int /*dtype*/, void* data_dev, 
     hipStreamSynchronize(st);
     hipFree(d);
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_zero_edges: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+// real_to_complex tail: out[m, s] = (-1)^m in[2m, s], m < nout, device arrays
+int pbh_decimate2(int device, void* hip_stream, int /*dtype*/, const void* in_dev, void* out_dev, int64_t nout,
+                  int nseries) {
+    if (!in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nout <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    HIPCHECK(hipSetDevice(device));
+    int64_t blocks = (nout * nseries + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_decimate2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, (const cf*)in_dev,
+                       (cf*)out_dev, nout, nseries);
+    HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
 

@@ -21,6 +21,7 @@
     int P##mix(int, void*, int, const void*, void*, int64_t, int, const double*);                               \
     int P##zero_edges(int, void*, int, void*, int64_t, int, const double*);                                     \
     int P##pol_basis(int, void*, int, const void*, void*, int64_t, int);                                        \
+    int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
@@ -120,6 +121,11 @@ int pbh_zero_edges(int device, void* stream, int dtype, void* data, int64_t n, i
 int pbh_pol_basis(int device, void* stream, int dtype, const void* in, void* out, int64_t np, int tc) {
     if (dtype == PBH_C128) return done(PBH_C128, pbh64_pol_basis(device, stream, dtype, in, out, np, tc));
     if (dtype == PBH_C64) return done(PBH_C64, pbh32_pol_basis(device, stream, dtype, in, out, np, tc));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_decimate2(int device, void* stream, int dtype, const void* in, void* out, int64_t nout, int ns) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_decimate2(device, stream, dtype, in, out, nout, ns));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_decimate2(device, stream, dtype, in, out, nout, ns));
     return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
 }
 int pbh_incoherent(int device, void* stream, const void* in, void* out, int64_t nout, int nchan, int unit, const int64_t* d) {

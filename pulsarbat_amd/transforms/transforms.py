@@ -3,7 +3,7 @@ rank 2).  Same FFT * H * IFFT skeleton as coherent dedispersion -- H is a phase 
 a band mask after a mixer (freq_shift) -- so both run on the plan pipeline of libpbhip.so with the
 transfer function generated on the device (``pbh_chirp_special``), plus two elementwise kernels
 (``pbh_mix``, ``pbh_zero_edges``).  Argument handling, broadcasting rules, zero fill, crop and
-``start_time`` bookkeeping follow the reference line by line.  Power-of-two lengths in this build.
+``start_time`` bookkeeping follow the reference line by line.  Any length (other than powers of two through the Bluestein plan).
 """
 
 import math
@@ -15,7 +15,7 @@ from .. import units as u
 from ..core import BasebandSignal
 from ..device import DeviceArray
 
-__all__ = ["time_shift", "freq_shift"]
+__all__ = ["time_shift", "freq_shift", "fast_len"]
 
 
 def _per_series(arr, z):
@@ -118,3 +118,9 @@ def freq_shift(z, /, shift):
         y = plan.dedisperse(DeviceArray(xm.tensor.reshape(N, S, 1)))
     out = _from_device(DeviceArray(y.tensor.reshape(N, S)), on_dev, False, dt, (N,) + tuple(z.sample_shape))
     return type(z).like(z, out)
+
+
+def fast_len(z, /):
+    """Crop a signal to the largest 7-smooth length <= len(z) (transforms.py:364-382)."""
+    from ..utils import prev_fast_len
+    return z[: prev_fast_len(len(z))]

@@ -1,0 +1,82 @@
+"""Handy utilities (reference pulsarbat/utils.py): ``real_to_complex`` on the HIP pipeline
+(SURVEY.md 8f rank 4), ``next_fast_len`` / ``prev_fast_len`` as plain host arithmetic."""
+
+from functools import lru_cache
+
+import numpy as np
+
+from . import _hip
+from .device import DeviceArray
+
+__all__ = ["real_to_complex", "next_fast_len", "prev_fast_len"]
+
+
+def real_to_complex(z, axis=0):
+    """Complex baseband representation of a real baseband signal (utils.py:15-65): analytic signal
+    via the FFT (Hilbert weights), shift by -B/2, decimate by 2.  ``float32 -> complex64``,
+    ``float64 -> complex128``.  numpy in -> numpy out, DeviceArray in -> DeviceArray out; the
+    arithmetic is the plan pipeline (FFT * h * IFFT) plus one decimating kernel.
+    """
+    on_dev = isinstance(z, DeviceArray)
+    if not on_dev:
+        z = np.asarray(z)
+    if np.dtype(z.dtype).kind == "c":
+        raise ValueError("Input must be real-valued.")
+    out_dtype = np.complex64 if z.dtype == np.float32 else np.complex128
+    N = z.shape[axis]
+    if N == 0:
+        return z.astype(out_dtype)
+    if N == 1:  # fft of one sample is itself, h = [1], no decimation
+        return z.astype(out_dtype)
+    # time on axis 0, everything else flattened into series (plumbing: views / one copy)
+    if on_dev:
+        t = z.tensor.movedim(axis, 0)
+        lead = tuple(t.shape[1:])
+        x = DeviceArray(t.reshape(N, -1).contiguous()).astype(out_dtype)
+    else:
+        a = np.moveaxis(z, axis, 0)
+        lead = a.shape[1:]
+        x = DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, -1)).astype(out_dtype))
+    S = x.shape[1]
+    with _hip.Plan(N, S, 1, 0, N, device=x.device_index, dtype=out_dtype) as plan:
+        plan.chirp_special(np.zeros(S), 2)
+        y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
+    out = _hip.decimate2(DeviceArray(y.tensor.reshape(N, S)))
+    nout = out.shape[0]
+    if on_dev:
+        return DeviceArray(out.tensor.reshape((nout,) + lead).movedim(0, axis).contiguous())
+    return np.ascontiguousarray(np.moveaxis(out.get().reshape((nout,) + tuple(lead)), 0, axis))
+
+
+def _smooth_7(limit):
+    """All 7-smooth numbers <= limit, ascending."""
+    vals = {1}
+    for p in (2, 3, 5, 7):
+        new = set()
+        for v in vals:
+            while v * p <= limit:
+                v *= p
+                new.add(v)
+        vals |= new
+    return sorted(vals)
+
+
+@lru_cache(maxsize=None)
+def next_fast_len(target):
+    """Smallest 7-smooth number >= target (utils.py:68-97)."""
+    target = int(target)
+    if target < 1:
+        raise ValueError("target must be a positive integer")
+    limit = 1
+    while limit < target:
+        limit *= 2
+    return next(v for v in _smooth_7(limit) if v >= target)
+
+
+@lru_cache(maxsize=None)
+def prev_fast_len(target):
+    """Largest 7-smooth number <= target (utils.py:100-130)."""
+    target = int(target)
+    if target < 1:
+        raise ValueError("target must be a positive integer")
+    return _smooth_7(target)[-1]
