@@ -35,11 +35,12 @@ def build(force=False, verbose=False):
     """Compile the HIP library if missing or older than its sources; returns its path."""
     if not force and not is_stale():
         return LIB
-    # -fno-slp-vectorize: v_pk_*_f32 has no rate advantage on gfx950 and its even-aligned register
+    # -fno-slp-vectorize: v_pk_*_f32 has no rate advantage on gfx950 (tools/micro/pkrate.hip) and its even-aligned register
     # pairs inflate VGPR pressure in the fully unrolled butterflies.
     # pbhip.hip is compiled twice: float32 (pbh32_*) and float64 (-DPBH_F64, pbh64_*); pbhip_api.cpp
     # owns the public pbh_* symbols and dispatches on the plan's dtype.
     common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
+    common += os.environ.get("PBH_EXTRA_FLAGS", "").split()  # e.g. -DPBH_DIAGNOSTIC for the ablation kernels
     jobs = [("pbhip32.o", common + ["-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
             ("pbhip64.o", common + ["-DPBH_F64", "-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
             ("pbhip_api.o", common + ["-x", "hip", "-c", "pbhip_api.cpp"])]

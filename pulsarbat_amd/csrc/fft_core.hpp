@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "pbh_config.hpp"
 
 namespace PBH_NS {
@@ -74,6 +77,8 @@ struct Dft;
 template <int DIR>
 struct Dft<1, DIR> {
     static __device__ __forceinline__ void run(cf (&)[1]) {}
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&)[1], TK tick) { tick(); }
 };
 template <int DIR>
 struct Dft<2, DIR> {
@@ -82,6 +87,8 @@ struct Dft<2, DIR> {
         v[0] = cadd(a, v[1]);
         v[1] = csub(a, v[1]);
     }
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&v)[2], TK tick) { run(v); tick(); }
 };
 template <int DIR>
 struct Dft<4, DIR> {
@@ -93,11 +100,18 @@ struct Dft<4, DIR> {
         v[1] = cadd(t1, t3);
         v[3] = csub(t1, t3);
     }
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&v)[4], TK tick) { run(v); tick(); }
 };
 // R = R1 * R2 with n = R2*n1 + n2, k = k1 + R1*k2:
 //   A[k1][n2] = W_R^{n2 k1} * sum_n1 x[R2 n1 + n2] W_R1^{n1 k1};  X[k1 + R1 k2] = sum_n2 A[k1][n2] W_R2^{n2 k2}
-template <int R1, int R2, int DIR>
-__device__ __forceinline__ void dft_composite(cf (&v)[R1 * R2]) {
+struct NoTick {
+    __device__ __forceinline__ void operator()() const {}
+};
+// tick(): called after every sub-transform of the OUTER composite level (R2 + R1 times for a radix-32
+// butterfly); kernels hang their global loads / stores on it to spread them through the arithmetic.
+template <int R1, int R2, int DIR, class TK = NoTick>
+__device__ __forceinline__ void dft_composite(cf (&v)[R1 * R2], TK tick = TK{}) {
     constexpr int R = R1 * R2;
     cf a[R2][R1];
 #pragma unroll
@@ -108,6 +122,7 @@ __device__ __forceinline__ void dft_composite(cf (&v)[R1 * R2]) {
         Dft<R1, DIR>::run(t);
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) a[n2][k1] = mul_w32<DIR>(t[k1], n2 * k1 * (32 / R));
+        tick();
     }
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
@@ -117,35 +132,58 @@ __device__ __forceinline__ void dft_composite(cf (&v)[R1 * R2]) {
         Dft<R2, DIR>::run(t);
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+        tick();
     }
 }
 template <int DIR>
 struct Dft<8, DIR> {
     static __device__ __forceinline__ void run(cf (&v)[8]) { dft_composite<2, 4, DIR>(v); }
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&v)[8], TK tick) { dft_composite<2, 4, DIR, TK>(v, tick); }
 };
 template <int DIR>
 struct Dft<16, DIR> {
     static __device__ __forceinline__ void run(cf (&v)[16]) { dft_composite<4, 4, DIR>(v); }
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&v)[16], TK tick) { dft_composite<4, 4, DIR, TK>(v, tick); }
 };
 template <int DIR>
 struct Dft<32, DIR> {
     static __device__ __forceinline__ void run(cf (&v)[32]) { dft_composite<4, 8, DIR>(v); }
+    template <class TK>
+    static __device__ __forceinline__ void run(cf (&v)[32], TK tick) { dft_composite<4, 8, DIR, TK>(v, tick); }
 };
 
 // ---- stage plan ------------------------------------------------------------------------------
 // Stages for length M with R points per thread: radix R while at least R remain, then one
 // stage of the remainder.
-constexpr int stage_radix(int M, int NS, int R) { return (M / NS >= R) ? R : (M / NS); }
+constexpr int kMaxRadix = 32;  // largest in-register DFT; R = 64 points per thread means two radix-32 butterflies
+constexpr int stage_radix(int M, int NS, int R) {
+    return (M / NS >= (R < kMaxRadix ? R : kMaxRadix)) ? (R < kMaxRadix ? R : kMaxRadix) : (M / NS);
+}
 // number of stage-twiddle seeds a thread needs for the stages starting at sub-length NS
 // (the last stage's butterflies q = 0..NB-1 share one seed: W_M^{(tau + q M/R) j} = (W_M^tau)^j W_R^{q j},
 //  and W_R^{q j} is a compile-time constant)
 constexpr int stage_seeds(int M, int NS, int R) {
-    return NS <= 1 ? 0 : (NS * stage_radix(M, NS, R) == M ? 1 : R / stage_radix(M, NS, R));
+    return NS <= 1 ? 0 : ((NS * stage_radix(M, NS, R) == M && R <= kMaxRadix) ? 1 : R / stage_radix(M, NS, R));
 }
 constexpr int tw_seeds(int M, int NS, int R) {
     return NS >= M ? 0 : (stage_seeds(M, NS, R) + tw_seeds(M, NS * stage_radix(M, NS, R), R));
 }
 constexpr int tw_seeds_or1(int M, int R) { return tw_seeds(M, 1, R) > 0 ? tw_seeds(M, 1, R) : 1; }
+// index of the stage that starts at sub-length NS, and the number of stages
+constexpr int stage_index(int M, int NS, int R) {
+    int s = 0;
+    for (int ns = 1; ns < NS; ns *= stage_radix(M, ns, R)) ++s;
+    return s;
+}
+constexpr int stage_count(int M, int R) { return stage_index(M, M, R); }
+// sub-length at which the last stage starts
+constexpr int last_stage_ns(int M, int R) {
+    int ns = 1;
+    while (ns * stage_radix(M, ns, R) < M) ns *= stage_radix(M, ns, R);
+    return ns;
+}
 
 // LDS addressing of a tile.  Logical slot L = pos * PS + fofs (8-byte slots).
 //   PAD = false: identity (column tiles with >= 16 interleaved FFTs are conflict-free as is)
@@ -188,7 +226,9 @@ __device__ __forceinline__ void load_tw_seeds(cf* w, int tau, const cf* __restri
     }
 }
 
-// t[j] *= w^j, j = 1..RAD-1, powers by a product tree of depth <= 5
+// t[j] *= w^j, j = 1..RAD-1.  Powers come from a product tree of depth <= 3 for w^1..w^7 and of depth
+// <= 5 for the block bases w^8, w^16, w^24; t[8b + j] gets (w^8b * w^j).  Only w^1..w^7 and one base are
+// live at a time (18 registers instead of the 34 a full table of powers needs).
 template <int RAD>
 __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
     if constexpr (RAD >= 2) t[1] = cmul(t[1], w1);
@@ -198,30 +238,28 @@ __device__ __forceinline__ void apply_powers(cf (&t)[RAD], cf w1) {
         t[2] = cmul(t[2], w2);
         t[3] = cmul(t[3], w3);
         if constexpr (RAD >= 8) {
-            cf w4 = csqr(w2);
-            cf w5 = cmul(w4, w1), w6 = csqr(w3), w7 = cmul(w4, w3);
-            t[4] = cmul(t[4], w4);
-            t[5] = cmul(t[5], w5);
-            t[6] = cmul(t[6], w6);
-            t[7] = cmul(t[7], w7);
-            if constexpr (RAD >= 16) {
-                cf p[16];  // w^8 .. w^15 in p[8..15]; w^1..w^7 reused below for RAD = 32
-                p[1] = w1; p[2] = w2; p[3] = w3; p[4] = w4; p[5] = w5; p[6] = w6; p[7] = w7;
-                p[8] = csqr(w4);
-                p[9] = cmul(p[8], w1);
-                p[10] = csqr(w5);
-                p[11] = cmul(p[8], w3);
-                p[12] = csqr(w6);
-                p[13] = cmul(p[8], w5);
-                p[14] = csqr(w7);
-                p[15] = cmul(p[8], w7);
+            cf p[8];
+            p[1] = w1; p[2] = w2; p[3] = w3;
+            p[4] = csqr(w2);
+            p[5] = cmul(p[4], w1);
+            p[6] = csqr(w3);
+            p[7] = cmul(p[4], w3);
 #pragma unroll
-                for (int j = 8; j < 16; ++j) t[j] = cmul(t[j], p[j]);
+            for (int j = 4; j < 8; ++j) t[j] = cmul(t[j], p[j]);
+            if constexpr (RAD >= 16) {
+                const cf w8 = csqr(p[4]);
+                t[8] = cmul(t[8], w8);
+#pragma unroll
+                for (int j = 1; j < 8; ++j) t[8 + j] = cmul(t[8 + j], cmul(w8, p[j]));
                 if constexpr (RAD >= 32) {
-                    cf w16 = csqr(p[8]);
+                    const cf w16 = csqr(w8);
                     t[16] = cmul(t[16], w16);
 #pragma unroll
-                    for (int j = 1; j < 16; ++j) t[16 + j] = cmul(t[16 + j], cmul(w16, p[j]));
+                    for (int j = 1; j < 8; ++j) t[16 + j] = cmul(t[16 + j], cmul(w16, p[j]));
+                    const cf w24 = cmul(w16, w8);
+                    t[24] = cmul(t[24], w24);
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) t[24 + j] = cmul(t[24 + j], cmul(w24, p[j]));
                 }
             }
         }
@@ -246,13 +284,28 @@ __device__ __forceinline__ void tile_sync() {
     }
 }
 
-template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false, bool WSYNC = false>
-__device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w) {
+// HK: optional hook the caller uses to spread its global-memory instructions over the transform
+// instead of issuing them in one burst (a burst blocks the in-order issue of every wave for
+// thousands of cycles).  hk(stage, -1) runs before each stage's butterflies; hk(stage, q) runs in
+// the LAST stage after butterfly q has put its outputs v[q + u*NB] in place (q is the unrolled loop
+// variable, a plain int).  The stage is a std::integral_constant so the hook can index register arrays.
+struct NoHook {
+    template <class A, class B>
+    __device__ __forceinline__ void operator()(A, B) const {}
+};
+struct tick_tag {};  // hk(stage, tick_tag{}) runs after every sub-transform of a stage's butterflies
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false, bool WSYNC = false, class HK = NoHook>
+__device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w, HK hk = HK{}) {
     if constexpr (NS < M) {
         constexpr int RAD = stage_radix(M, NS, R);
         constexpr int NB = R / RAD;
         constexpr int MR = M / R;
         constexpr bool LAST = (NS * RAD == M);
+        constexpr int SI = stage_index(M, NS, R);
+        hk(ic<SI>{}, ic<-1>{});
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             cf t[RAD];
@@ -261,18 +314,21 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
             int jb = tau + q * MR;
             int k = jb & (NS - 1);
             if constexpr (NS > 1) {
-                cf w1 = w[(LAST && NB > 1) ? 0 : q];
+                constexpr bool ONE_SEED = LAST && NB > 1 && R <= kMaxRadix;
+                cf w1 = w[ONE_SEED ? 0 : q];
                 if (DIR > 0) w1 = cconj(w1);
                 apply_powers<RAD>(t, w1);
-                if constexpr (LAST && NB > 1) {
+                if constexpr (ONE_SEED) {
 #pragma unroll
                     for (int j = 1; j < RAD; ++j) t[j] = mul_w32<DIR>(t[j], q * j * (32 / R));
                 }
             }
-            Dft<RAD, DIR>::run(t);
+            if constexpr (std::is_same<HK, NoHook>::value) Dft<RAD, DIR>::run(t);
+            else Dft<RAD, DIR>::run(t, [&]() { hk(ic<SI>{}, tick_tag{}); });
             if constexpr (LAST) {
 #pragma unroll
                 for (int u = 0; u < RAD; ++u) v[q + u * NB] = t[u];
+                hk(ic<SI>{}, q);
             } else if constexpr (XS) {
                 // split exchange (half the LDS): park the butterfly outputs back in v; the real and
                 // imaginary parts go through a float buffer one after the other below
@@ -315,7 +371,7 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 }
                 __syncthreads();
             }
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS>(v, lds, tau, fofs, w + stage_seeds(M, NS, R));
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, false, HK>(v, lds, tau, fofs, w + stage_seeds(M, NS, R), hk);
         } else if constexpr (!LAST) {
             tile_sync<WSYNC>();
             constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
@@ -328,9 +384,18 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 for (int i = 0; i < R; ++i) v[i] = lds[lds_phys<PAD>((tau + i * MR) * PS + fofs)];
             }
             tile_sync<WSYNC>();
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, WSYNC>(v, lds, tau, fofs, w + stage_seeds(M, NS, R));
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, WSYNC, HK>(v, lds, tau, fofs, w + stage_seeds(M, NS, R), hk);
         }
     }
+}
+
+// Make the compiler forget where a register value came from (stops LICM from hoisting the twiddle
+// power trees out of a persistent loop).  A fold expression, NOT a loop: a loop over asm volatile
+// is not unrolled, which would put the array in scratch memory and a vmcnt(0) behind every reload.
+__device__ __forceinline__ void launder1(cf& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
+template <int... I>
+__device__ __forceinline__ void launder_all(cf* a, std::integer_sequence<int, I...>) {
+    (launder1(a[I]), ...);
 }
 
 // ---- buffer (SRD) addressing: wave-uniform base in SGPRs, 32-bit per-lane offset, scalar step ----

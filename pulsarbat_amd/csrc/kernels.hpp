@@ -100,7 +100,7 @@ __device__ __forceinline__ bool col_decode(const ColParams& p, int64_t tile, int
 // LDS exchange: 64 KiB instead of 128 KiB and a 128-VGPR cap, so TWO workgroups share a CU and
 // one's loads/stores overlap the other's butterflies.
 template <int M, int OP, int R, bool XS>
-__global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p) {
+__global__ __launch_bounds__(kTilePoints / R, XS ? (2 * kTilePoints / R) / 256 : 1) void k_col(ColParams p) {
     constexpr int F = kTilePoints / M;  // columns per tile
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;           // row stride between a thread's points
@@ -154,6 +154,176 @@ __global__ __launch_bounds__(kTilePoints / R, XS ? 4 : 1) void k_col(ColParams p
     }
 }
 
+// ---- persistent column pass for the planar, in-place case (planar5's passes 2 and 4) ------------------
+// One workgroup per CU (128 KiB of LDS admits one) walks over tiles (series s, 16-column group g).
+// History: a first persistent version that stored each tile as soon as it was ready and
+// walked tiles with a static stride was SLOWER than one-tile workgroups (1.11 vs 0.98 ms); the two
+// things that made the persistent form win are in k_colq's header below.
+struct ColpParams {
+    cf* data;          // planar work buffer: series s at s * plane, row r at r * N2
+    int64_t plane;
+    int S, N2;
+    BigTwiddle tw;     // W_N, N = M * N2
+    const cf* tw16k;
+    int64_t crop_start, crop_stop;  // OP_TW_INV: keep time index t in [start, stop), t = row*N2 + n2
+    int order;         // tile order: 0 = column groups of one series consecutive, 1 = series fastest
+    unsigned* counter; // k_colq: dynamic tile hand-out (zeroed before the launch); null = static stride
+};
+
+// ---- persistent column pass with deferred, interleaved stores --------------------------------------
+// As k_colp, but the outputs of tile i are not stored when they are ready: a burst of 32 stores per
+// thread blocks the wave until the write path has taken 128 KiB (writes are the slow direction: the
+// burst alone is ~45 % of an iteration).  Instead they stay in registers and are stored during tile
+// i+1's butterflies, two at a time at fft_tile's tick points, each followed by the load of the same
+// slot of tile i+2 -- the slot's registers pass from "output waiting to be stored" to "input on its
+// way", so the budget is two tiles of registers (the one being transformed, and the out/in slots).  Out-of-range descriptors (0 bytes) turn the first
+// iteration's stores and the last iterations' loads into no-ops without branches.
+template <int M, int OP, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
+    constexpr int F = kTilePoints / M;
+    constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+
+    const int tid = threadIdx.x;
+    const int f = tid % F, tau = tid / F;
+    const uint32_t ngrp = (uint32_t)(p.N2 / F);
+    const uint32_t ntile = ngrp * (uint32_t)p.S;
+    const int voff = (tau * p.N2 + f) * (int)sizeof(cf);
+    const int stepb = MR * p.N2 * (int)sizeof(cf);
+    const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * p.N2 + F) * (int64_t)sizeof(cf));
+    const int shift = p.tw.shift;
+    const int64_t lomask = (1LL << shift) - 1;
+    const uint32_t c0 = (uint32_t)p.crop_start, c1 = (uint32_t)p.crop_stop;
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+
+    auto group_of = [&](uint32_t t) -> int { return p.order ? (int)(t / (uint32_t)p.S) : (int)(t % ngrp); };
+    auto series_of = [&](uint32_t t) -> int { return p.order ? (int)(t % (uint32_t)p.S) : (int)(t / ngrp); };
+    auto tile_rsrc = [&](uint32_t t) {
+        return t < ntile ? make_rsrc(p.data + (int64_t)series_of(t) * p.plane + (int64_t)group_of(t) * F, tile_bytes)
+                         : make_rsrc(p.data, 0);
+    };
+    auto load_tables = [&](int n2, double2& bh, double2& bl, double2& sh, double2& sl) {
+        const int64_t pb = ((int64_t)n2 * tau) & p.tw.mask, ps = ((int64_t)n2 * MR) & p.tw.mask;
+        bh = p.tw.hi[pb >> shift];
+        bl = p.tw.lo[pb & lomask];
+        sh = p.tw.hi[ps >> shift];
+        sl = p.tw.lo[ps & lomask];
+    };
+
+    // Tile order.  The first two tiles of a workgroup are static (b, b + G); after that tiles are handed
+    // out by an atomic counter when p.counter is set, one iteration ahead through an LDS slot, so the
+    // tiles in flight across the chip stay a tight window of consecutive column groups (what hardware
+    // dispatch of one-tile workgroups gives, and what DRAM pages like) however the workgroups drift.
+    const uint32_t G = gridDim.x;
+    unsigned* slot = reinterpret_cast<unsigned*>(smem + lds_tile_bytes<PAD>());
+    uint32_t t = blockIdx.x;
+    if (t >= ntile) return;
+    uint32_t tn = t + G;
+    int g = group_of(t);
+    rsrc_t rd = tile_rsrc(t);            // tile in v
+    rsrc_t rdo = make_rsrc(p.data, 0);   // tile whose outputs wait in `out` (none yet)
+    uint32_t tto = 0;                    // time index of that tile's first sample in this thread (N < 2^31)
+    const uint32_t rowstep = (uint32_t)MR * (uint32_t)p.N2;
+    double2 zbh, zbl, zsh, zsl;
+    load_tables(g * F + f, zbh, zbl, zsh, zsl);
+    cf v[R], out[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        v[i] = buf_load(rd, voff, i * stepb);
+        out[i] = make_cf(0, 0);
+    }
+
+    while (true) {
+        launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
+        const int n2 = g * F + f;
+        const double2 zb = zmul(zbh, zbl), zs = zmul(zsh, zsl);
+        const bool more = tn < ntile;
+        // the tile after next: requested now, its index parked in LDS after the butterflies (the atomic's
+        // round trip must not be waited for here)
+        unsigned fetched = tn + G;
+        if (tid == 0 && p.counter) fetched = 2 * G + atomicAdd(p.counter, 1u);
+        const rsrc_t rd2 = tile_rsrc(tn);          // tile whose samples are requested during this iteration
+        cf in2[R];                                 // ... into the registers the stored outputs leave
+        int cnt = 0;
+        auto pump = [&](int n) {                   // store n waiting outputs, request n samples
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                if (cnt < R) {
+                    if constexpr (OP == OP_TW_INV) {
+                        // cropped samples: an out-of-range offset makes the hardware drop the store (no branch)
+                        const uint32_t tt = tto + (uint32_t)cnt * rowstep;
+                        buf_store(rdo, (tt >= c0 && tt < c1) ? voff : (int)0x80000000, cnt * stepb, out[cnt]);
+                    } else {
+                        buf_store(rdo, voff, cnt * stepb, out[cnt]);
+                    }
+                    in2[cnt] = buf_load(rd2, voff, cnt * stepb);
+                    ++cnt;
+                }
+            }
+        };
+        auto hk = [&](auto st, auto q) {
+            if constexpr (std::is_same<decltype(q), tick_tag>::value) {
+                __builtin_amdgcn_sched_barrier(0x38E);  // VALU / SALU / LDS may move across, global memory ops stay put
+                pump(2);
+                __builtin_amdgcn_sched_barrier(0x38E);
+            }
+        };
+        if constexpr (OP == OP_TW_INV) {
+            double2 z = zb;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                v[i] = cmul(v[i], make_cf((real)z.x, (real)-z.y));
+                z = zmul(z, zs);
+            }
+            fft_tile<M, 1, R, +1, F, PAD, false, false>(v, lds, tau, f, w, hk);
+        } else {
+            fft_tile<M, 1, R, -1, F, PAD, false, false>(v, lds, tau, f, w, hk);
+        }
+        pump(R);  // whatever the ticks did not reach (short transforms)
+        if (tid == 0) slot[0] = fetched;
+        __syncthreads();
+        const uint32_t tnn = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);  // wave-uniform: descriptors stay in SGPRs
+        // tables of the next tile: after every request above, before nothing that has to wait for them
+        const int gn = more ? group_of(tn) : g;
+        if (more) load_tables(gn * F + f, zbh, zbl, zsh, zsl);
+        if constexpr (OP == OP_TW_INV) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) out[i] = v[i];
+        } else {
+            double2 z = zb;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                out[i] = cmul(v[i], make_cf((real)z.x, (real)z.y));
+                z = zmul(z, zs);
+            }
+        }
+        rdo = rd;
+        tto = (uint32_t)tau * (uint32_t)p.N2 + (uint32_t)n2;
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = in2[i];
+        __syncthreads();   // everyone has read the slot before thread 0 overwrites it
+        t = tn;
+        tn = tnn;
+        g = gn;
+        rd = rd2;
+    }
+    // drain: the last tile's outputs
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if constexpr (OP == OP_TW_INV) {
+            const uint32_t tt = tto + (uint32_t)i * rowstep;
+            buf_store(rdo, (tt >= c0 && tt < c1) ? voff : (int)0x80000000, i * stepb, out[i]);
+        } else {
+            buf_store(rdo, voff, i * stepb, out[i]);
+        }
+    }
+}
+
 // ---- fused row pass --------------------------------------------------------------------------------
 struct RowParams {
     cf* data;          // planar rows, in place: row r at r * M
@@ -162,6 +332,9 @@ struct RowParams {
     int64_t nrows;     // S * N1
     int N1, npol;
     int perm_w;        // chirp row order (see ChirpParams::perm_w); 8 selects k_row2
+#ifdef PBH_DIAGNOSTIC
+    unsigned long long* dbg;  // ABL = 4: [block][iteration < 64][8] s_memtime stamps
+#endif
 };
 
 // Persistent, software-pipelined: a workgroup walks over tiles; while tile i is transformed the
@@ -171,9 +344,14 @@ struct RowParams {
 // Tile order: the pols of one (channel, k1) run back to back on the same workgroup so the second
 // one finds the chirp row in L2/MALL instead of HBM.
 // ABL (diagnostic builds only): 0 = product kernel, 1 = no FFTs (memory traffic only),
-// 2 = no chirp loads (constant multiplier), 3 = neither loads nor stores after the first tile
-template <int M, int R, bool PF, int ABL = 0>
+// 2 = no chirp loads (constant multiplier), 3 = neither loads nor stores after the first tile,
+// 4 = product arithmetic with forced waits and s_memtime stamps per phase (timeline of one wave),
+// 5 = ablation 3 with the stamps (shader clock without memory traffic)
+// SP = 1: the chirp loads, the next tile's loads and the stores are spread over the stages of the
+// two transforms through fft_tile's hook instead of being issued in three bursts.
+template <int M, int R, bool PF, int ABL = 0, int SP = 0>
 __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
+    constexpr int NST = stage_count(M, R);
     constexpr int FR = kTilePoints / M;  // rows per tile
     constexpr int MR = M / R;
     constexpr int STEP = MR * (int)sizeof(cf);
@@ -212,21 +390,60 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
 #pragma unroll
     for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
 
+#ifdef PBH_DIAGNOSTIC
+    int iter = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (ABL >= 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && iter < 64) p.dbg[((int64_t)blockIdx.x * 64 + iter) * 8 + slot] = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto wait_vm = [&](int left) {  // s_waitcnt vmcnt(left), gfx9 encoding
+        if constexpr (ABL == 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (left == 32) __builtin_amdgcn_s_waitcnt((32 & 0xF) | ((32 >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+            else __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#else
+    auto stamp = [&](int) {};
+    auto wait_vm = [&](int) {};
+#endif
     while (true) {
+        stamp(0);
+        wait_vm(32);  // x of this tile (the previous tile's stores may still be in flight)
+        stamp(1);
         // keep the twiddle-power trees inside the iteration: hoisted out of the loop they would
         // pin ~140 VGPRs (LICM), which is what the prefetch registers need
-#pragma unroll
-        for (int i = 0; i < tw_seeds_or1(M, R); ++i) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
+        launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
         const int64_t srs = r0 / p.N1;
         const int k1 = (int)(r0 - srs * p.N1);
         const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M,
                                     (uint32_t)(FR * (int64_t)M * sizeof(cf)));
         if constexpr (PF) {
             cf c[R];
+            if constexpr (SP && NST >= 2) {
+                // chirp row requested during the first NST-1 stages (consumed right after the last one)
+                auto hk = [&](auto st, auto q) {
+                    constexpr int ST = decltype(st)::value;
+                    if constexpr (std::is_same<decltype(q), ic<-1>>::value && ST < NST - 1) {
 #pragma unroll
-            for (int i = 0; i < R; ++i)
-                c[i] = (ABL == 2 || ABL == 3) ? make_cf(RC(0.999), RC(0.001) * i) : buf_load(rc, voff, i * STEP);
-            if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
+                        for (int i = ST * R / (NST - 1); i < (ST + 1) * R / (NST - 1); ++i) c[i] = buf_load(rc, voff, i * STEP);
+                    }
+                };
+                fft_tile<M, 1, R, -1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    c[i] = (ABL == 2 || ABL == 3 || ABL == 5) ? make_cf(RC(0.999), RC(0.001) * i) : buf_load(rc, voff, i * STEP);
+                if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
+            }
+            stamp(2);
+            wait_vm(0);  // chirp row (and the previous stores)
+            stamp(3);
 #pragma unroll
             for (int i = 0; i < R; ++i) v[i] = cmul(v[i], c[i]);
         } else {
@@ -241,16 +458,38 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         const rsrc_t rdn = more ? data_rsrc(rn) : make_rsrc(p.data, 0);
         if constexpr (PF) {
             cf nx[R];
+            if constexpr (SP && NST >= 2) {
+                // next tile requested stage by stage; outputs stored as the last stage produces them
+                constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);  // butterflies per thread in the last stage
+                auto hk = [&](auto st, auto q) {
+                    constexpr int ST = decltype(st)::value;
+                    if constexpr (std::is_same<decltype(q), ic<-1>>::value) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) nx[i] = (ABL == 3) ? v[i] : buf_load(rdn, voff, i * STEP);
-            if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
-            if (ABL != 3 || !more) {
+                        for (int i = ST * R / NST; i < (ST + 1) * R / NST; ++i) nx[i] = buf_load(rdn, voff, i * STEP);
+                    } else if constexpr (!std::is_same<decltype(q), tick_tag>::value) {
 #pragma unroll
-                for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
+                        for (int u = 0; u < R / NBL; ++u) buf_store(rd, voff, (q + u * NBL) * STEP, v[q + u * NBL]);
+                    }
+                };
+                fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) nx[i] = (ABL == 3 || ABL == 5) ? v[i] : buf_load(rdn, voff, i * STEP);
+                stamp(4);
+                if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
+                stamp(5);
+                if ((ABL != 3 && ABL != 5) || !more) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
+                }
             }
+            stamp(6);
+#ifdef PBH_DIAGNOSTIC
+            ++iter;
+#endif
             if (!more) break;
 #pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = (ABL == 3) ? make_cf(v[i].x + nx[i].y, v[i].y) : nx[i];
+            for (int i = 0; i < R; ++i) v[i] = (ABL == 3 || ABL == 5) ? make_cf(v[i].x + nx[i].y, v[i].y) : nx[i];
         } else {
             fft_tile<M, 1, R, +1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
@@ -335,10 +574,8 @@ __global__ __launch_bounds__(512) void k_row2(RowParams p) {
     for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff_t, i * STEPT);
 
     while (true) {
-#pragma unroll
-        for (int i = 0; i < tw_seeds_or1(MW, R); ++i) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(wq[c].x), "+v"(wq[c].y));
+        launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(MW, R)>{});
+        launder_all(wq, std::make_integer_sequence<int, 4>{});
         const int64_t srs = r0 / p.N1;
         const int k1 = (int)(r0 - srs * p.N1);
         const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M, ROWB);

@@ -180,11 +180,35 @@ static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
     if (ntile > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "too many column tiles");
     prm.ntile = (int)ntile;
     // (a split re/im exchange variant, k_col<..., true>, gives two workgroups per CU; it measured
-    //  slower -- 1.14 vs 0.98 ms -- because the 128-VGPR cap spills: not instantiated)
+    //  slower -- 1.14 vs 0.98 ms -- because the 128-VGPR cap spills ~30 registers; 64 points per thread x
+    //  256 threads spills too: not instantiated)
     // (cache-policy experiments on the partial-line variants: non-temporal loads/stores 2-3x slower --
     //  they defeat the L2 merging --, sc1 loads -5 % at best)
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_col<m, OP, PBH_R, false>, prm, ntile, kTilePoints / PBH_R, st);
+        FOR_ALL_M(X)
+#undef X
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "column pass length " + std::to_string(M));
+}
+
+// persistent planar in-place column pass (planar5).  PBH_COLP: 0 = one-tile workgroups (k_col),
+// 1 = k_colq with a static tile stride, 2 (default) = k_colq with tiles handed out by an atomic counter
+static int colp_mode() {
+    static int m = [] { const char* e = getenv("PBH_COLP"); return e ? atoi(e) : 2; }();
+    return m;
+}
+template <int OP>
+static int launch_colq(int M, ColpParams prm, hipStream_t st) {
+    const int F = kTilePoints / M;
+    if (prm.N2 % F != 0) return fail(PBH_ERR_STATE, "k_colq needs whole column groups");
+    prm.order = 0;
+    int64_t tiles = (int64_t)prm.S * (prm.N2 / F);
+    if (tiles > row_grid()) tiles = row_grid();
+    if (colp_mode() < 2) prm.counter = nullptr;
+    if (prm.counter) HIPCHECK(hipMemsetAsync(prm.counter, 0, sizeof(unsigned), st));
+    switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_colq<m, OP, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, ((kTilePoints / m) < 16 ? lds_tile_bytes<true>() : lds_tile_bytes<false>()) + 16);
         FOR_ALL_M(X)
 #undef X
     }
@@ -200,10 +224,38 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     if (M == 16384 && abl == 1) return launch_tile_kernel(k_row<16384, 32, true, 1>, prm, tiles, 512, st);
     if (M == 16384 && abl == 2) return launch_tile_kernel(k_row<16384, 32, true, 2>, prm, tiles, 512, st);
     if (M == 16384 && abl == 3) return launch_tile_kernel(k_row<16384, 32, true, 3>, prm, tiles, 512, st);
+    if (M == 16384 && (abl == 4 || abl == 5)) {  // phase timeline: every launch synchronises and rewrites $PBH_ROW_DBG
+        static unsigned long long* dbg = nullptr;
+        const int64_t dbg_n = (int64_t)row_grid() * 64 * 8;
+        if (!dbg) HIPCHECK(hipMalloc(&dbg, dbg_n * sizeof(unsigned long long)));
+        HIPCHECK(hipMemsetAsync(dbg, 0, dbg_n * sizeof(unsigned long long), st));
+        RowParams q = prm;
+        q.dbg = dbg;
+        const int rc = abl == 4 ? launch_tile_kernel(k_row<16384, 32, true, 4>, q, tiles, 512, st)
+                                : launch_tile_kernel(k_row<16384, 32, true, 5>, q, tiles, 512, st);
+        if (rc != PBH_OK) return rc;
+        if (const char* path = getenv("PBH_ROW_DBG")) {
+            HIPCHECK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h((size_t)dbg_n);
+            HIPCHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE* fh = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), fh); fclose(fh); }
+        }
+        return PBH_OK;
+    }
 #endif
 #ifndef PBH_F64
     if (prm.perm_w == 8) return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
 #endif
+    // spread issue (memory instructions distributed over the stages) is the product path: 1.11 vs 1.16 ms
+    // for the burst form at config 2; PBH_ROW_SPREAD=0 selects the burst kernel for A/B runs
+    static const bool spread = [] { const char* e = getenv("PBH_ROW_SPREAD"); return e ? atoi(e) != 0 : true; }();
+    if (spread) {
+        switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 1>, prm, tiles, kTilePoints / PBH_R, st);
+            FOR_ROW_M(X)
+#undef X
+        }
+    }
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st);
         FOR_ROW_M(X)
@@ -338,12 +390,20 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             return launch_deinterleave(in, work, N, S, st);
         }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
-        steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
+        const bool colp = colp_mode() != 0 && N2 % (kTilePoints / N1) == 0 && N < (1LL << 31);
+        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
+        ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
+        steps.push_back({"k_col_fwd", [=](hipStream_t st) {
+            return colp ? launch_colq<OP_FWD_TW>(N1, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
+        }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
-        steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
+        ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
+        steps.push_back({"k_col_inv", [=](hipStream_t st) {
+            return colp ? launch_colq<OP_TW_INV>(N1, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
+        }});
         if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
@@ -552,7 +612,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
             double a = -2.0 * M_PI * (double)i / (double)kTwTable;
             h[i] = make_cf((real)cos(a), (real)sin(a));
         }
-        if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable)) != PBH_OK) return bail(rc);
+        if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable + 16)) != PBH_OK) return bail(rc);  // + k_colq's tile counters
         if (hipMemcpy(p->tw16k, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(PBH_ERR_HIP, "hipMemcpy(tw16k) failed"));
     }
