@@ -21,6 +21,7 @@ struct ChirpParams {
     int N1, N2, nchan;
     real scale;
     int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
+    float* phase = nullptr;  // optional second output, same order: the chirp's phase in revolutions, [-0.5, 0.5]
 };
 
 __device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w) {
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
         sincospi(2.0 * fr, &sn, &cs);
         // the reference rounds the transfer function to complex64 (dedispersion.py:23) for both data dtypes
         p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
+        if (p.phase) p.phase[d] = (float)(-fr);   // chirp = exp(2 pi i phase): what k_rowp feeds to v_cos / v_sin
     }
 }
 

@@ -332,6 +332,7 @@ struct RowParams {
     int64_t nrows;     // S * N1
     int N1, npol;
     int perm_w;        // chirp row order (see ChirpParams::perm_w); 8 selects k_row2
+    unsigned* counter; // SP = 2: dynamic tile hand-out (zeroed before the launch); null = static stride
 #ifdef PBH_DIAGNOSTIC
     unsigned long long* dbg;  // ABL = 4: [block][iteration < 64][8] s_memtime stamps
 #endif
@@ -389,6 +390,10 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     cf v[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
+    // SP = 2: tiles after the first two of a workgroup come from an atomic counter, fetched one
+    // iteration ahead and passed through an LDS slot (see k_colq)
+    unsigned* slot = reinterpret_cast<unsigned*>(smem + lds_tile_bytes<true>());
+    int64_t tnx = t + gridDim.x;
 
 #ifdef PBH_DIAGNOSTIC
     int iter = 0;
@@ -419,13 +424,34 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         // keep the twiddle-power trees inside the iteration: hoisted out of the loop they would
         // pin ~140 VGPRs (LICM), which is what the prefetch registers need
         launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
+        unsigned fetched = (unsigned)(tnx + gridDim.x);
+        if constexpr (SP == 2) {
+            if (tid == 0 && p.counter) fetched = 2 * gridDim.x + atomicAdd(p.counter, 1u);
+        }
         const int64_t srs = r0 / p.N1;
         const int k1 = (int)(r0 - srs * p.N1);
         const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M,
                                     (uint32_t)(FR * (int64_t)M * sizeof(cf)));
         if constexpr (PF) {
             cf c[R];
-            if constexpr (SP && NST >= 2) {
+            if constexpr (SP == 2) {
+                // chirp row requested two loads per tick (pinned), i.e. within the first 16 of the ~40 ticks
+                int cnt = 0;
+                auto hk = [&](auto st, auto q) {
+                    if constexpr (std::is_same<decltype(q), tick_tag>::value) {
+                        __builtin_amdgcn_sched_barrier(0x38E);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            if (cnt < R) { c[cnt] = buf_load(rc, voff, cnt * STEP); ++cnt; }
+                        __builtin_amdgcn_sched_barrier(0x38E);
+                    }
+                };
+                fft_tile<M, 1, R, -1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (cnt < R) { c[cnt] = buf_load(rc, voff, cnt * STEP); ++cnt; }
+                if (tid == 0) slot[0] = fetched;
+            } else if constexpr (SP && NST >= 2) {
                 // chirp row requested during the first NST-1 stages (consumed right after the last one)
                 auto hk = [&](auto st, auto q) {
                     constexpr int ST = decltype(st)::value;
@@ -452,13 +478,36 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
             for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, voff, i * STEP));
         }
 
-        const int64_t tn = t + gridDim.x;
+        const int64_t tn = SP == 2 ? tnx : t + gridDim.x;
         const bool more = tn < ntile;
         const int64_t rn = more ? first_row(tn) : r0;
         const rsrc_t rdn = more ? data_rsrc(rn) : make_rsrc(p.data, 0);
         if constexpr (PF) {
             cf nx[R];
-            if constexpr (SP && NST >= 2) {
+            if constexpr (SP == 2) {
+                constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);
+                int cnt = 0;
+                auto hk = [&](auto st, auto q) {
+                    if constexpr (std::is_same<decltype(q), tick_tag>::value) {
+                        __builtin_amdgcn_sched_barrier(0x38E);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }
+                        __builtin_amdgcn_sched_barrier(0x38E);
+                    } else if constexpr (!std::is_same<decltype(q), ic<-1>>::value) {
+                        __builtin_amdgcn_sched_barrier(0x38E);
+#pragma unroll
+                        for (int u = 0; u < R / NBL; ++u) buf_store(rd, voff, (q + u * NBL) * STEP, v[q + u * NBL]);
+                        __builtin_amdgcn_sched_barrier(0x38E);
+                    }
+                };
+                fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }
+                if constexpr (NST < 2) __syncthreads();
+                tnx = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)slot[0]);
+            } else if constexpr (SP && NST >= 2) {
                 // next tile requested stage by stage; outputs stored as the last stage produces them
                 constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);  // butterflies per thread in the last stage
                 auto hk = [&](auto st, auto q) {
@@ -503,6 +552,119 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         rd = rdn;
     }
 }
+
+// ---- fused row pass fed by the chirp's PHASE (float32 only, one row per tile) ---------------------------
+// k_row reads the complex64 chirp row once per polarisation: 8 B per sample of traffic for 4 B of
+// algorithmic need (the second read does not hit in L2: a CU streams ~12 MiB between the two uses).
+// Here the unit of work is a (channel, k1) PAIR: the row's phase (4 B per bin, float32 revolutions,
+// written by k_chirp next to the complex64 chirp) is loaded once, stays in 32 VGPRs while the
+// polarisations are transformed one after the other, and cos / sin come from the hardware
+// (v_cos_f32 / v_sin_f32 take revolutions; max error 1.4e-7, rms 4.9e-8: tools/micro/sincos.hip --
+// the same size as the complex64 rounding of the reference's chirp).  Chirp traffic: 8 -> 2 B/sample.
+// Pairs are handed out by an atomic counter (one pair ahead, through an LDS slot); the next tile's
+// samples are requested two per tick of the inverse transform and the stores are pinned to the last
+// stage's butterflies.
+#ifndef PBH_F64
+struct RowpParams {
+    cf* data;            // planar rows, in place: row r at r * M
+    const float* phase;  // plan order [chan][k1][k2], revolutions
+    const cf* tw16k;
+    int nchan, N1, npol;
+    real scale;          // 1/N
+    unsigned* counter;   // pair hand-out (zeroed before the launch); null = static stride
+};
+
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
+    static_assert(M == kTilePoints, "k_rowp: one row per tile");
+    constexpr int MR = M / R;
+    constexpr int STEP = MR * (int)sizeof(cf), PSTEP = MR * (int)sizeof(float);
+    constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    unsigned* slot = reinterpret_cast<unsigned*>(smem + lds_tile_bytes<true>());
+
+    const int tau = threadIdx.x;
+    const int voff = tau * (int)sizeof(cf), pvoff = tau * (int)sizeof(float);
+    const uint32_t npair = (uint32_t)p.nchan * (uint32_t)p.N1;
+    const uint32_t G = gridDim.x;
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+
+    auto row_rsrc = [&](uint32_t u, int pol) {
+        if (u >= npair) return make_rsrc(p.data, 0);
+        const uint32_t chan = u / (uint32_t)p.N1, k1 = u - chan * (uint32_t)p.N1;
+        const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + k1;
+        return make_rsrc(p.data + row * M, (uint32_t)(M * sizeof(cf)));
+    };
+
+    uint32_t u = blockIdx.x;
+    if (u >= npair) return;
+    uint32_t unx = u + G;   // pair after this one
+    int pol = 0;
+    rsrc_t rd = row_rsrc(u, 0);
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
+    float ph[R];
+    unsigned fetched = 0;
+
+    while (true) {
+        launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
+        if (pol == 0) {   // wave-uniform: a new pair -- its phase row, and the index of the pair after next
+            const rsrc_t rp = make_rsrc(p.phase + (int64_t)u * M, (uint32_t)(M * sizeof(float)));
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));
+            fetched = unx + G;
+            if (tau == 0 && p.counter) fetched = 2 * G + atomicAdd(p.counter, 1u);
+        }
+        fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, 0, w);
+        if (pol == 0 && tau == 0) slot[0] = fetched;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const cf c = make_cf(__builtin_amdgcn_cosf(ph[i]) * p.scale, __builtin_amdgcn_sinf(ph[i]) * p.scale);
+            v[i] = cmul(v[i], c);
+        }
+
+        const bool last_pol = pol == p.npol - 1;
+        const uint32_t un = last_pol ? unx : u;
+        const int poln = last_pol ? 0 : pol + 1;
+        const bool more = un < npair;
+        const rsrc_t rdn = row_rsrc(un, poln);
+        cf nx[R];
+        int cnt = 0;
+        auto hk = [&](auto st, auto q) {
+            if constexpr (std::is_same<decltype(q), tick_tag>::value) {
+                __builtin_amdgcn_sched_barrier(0x38E);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }
+                __builtin_amdgcn_sched_barrier(0x38E);
+            } else if constexpr (!std::is_same<decltype(q), ic<-1>>::value) {
+                __builtin_amdgcn_sched_barrier(0x38E);
+#pragma unroll
+                for (int k = 0; k < R / NBL; ++k) buf_store(rd, voff, (q + k * NBL) * STEP, v[q + k * NBL]);
+                __builtin_amdgcn_sched_barrier(0x38E);
+            }
+        };
+        fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, 0, w, hk);
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = nx[i];
+        if (last_pol) {
+            u = unx;
+            unx = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);
+        }
+        pol = poln;
+        rd = rdn;
+    }
+}
+#endif  // !PBH_F64
 
 // ---- forward-only row FFT, in place (builds the Bluestein kernel's spectrum in plan order) -------------------
 template <int M, int R>

@@ -90,6 +90,8 @@ struct pbh_plan {
 
     cf* work = nullptr;      // planar workspace, S * N
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
+    float* chirp_phase = nullptr;  // same order, revolutions: what k_rowp reads (generated chirps only)
+    bool has_phase = false;
     cf* tw16k = nullptr;     // W_16384^p
     double2* tw_hi = nullptr;
     double2* tw_lo = nullptr;
@@ -246,9 +248,19 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
 #ifndef PBH_F64
     if (prm.perm_w == 8) return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
 #endif
-    // spread issue (memory instructions distributed over the stages) is the product path: 1.11 vs 1.16 ms
-    // for the burst form at config 2; PBH_ROW_SPREAD=0 selects the burst kernel for A/B runs
-    static const bool spread = [] { const char* e = getenv("PBH_ROW_SPREAD"); return e ? atoi(e) != 0 : true; }();
+    // PBH_ROW_SPREAD: 0 = three bursts, 1 = per stage, 2 = per tick (pinned), 3 (default) = per tick + tiles
+    // handed out by an atomic counter.  Config 2: 1.16 / 1.14 / 1.11 / 1.085 ms.
+    static const int spread = [] { const char* e = getenv("PBH_ROW_SPREAD"); return e ? atoi(e) : 3; }();
+    if (spread >= 2) {
+        RowParams q = prm;
+        if (spread == 2) q.counter = nullptr;
+        if (q.counter) HIPCHECK(hipMemsetAsync(q.counter, 0, sizeof(unsigned), st));
+        switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 2>, q, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+            FOR_ROW_M(X)
+#undef X
+        }
+    }
     if (spread) {
         switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 1>, prm, tiles, kTilePoints / PBH_R, st);
@@ -263,6 +275,20 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     }
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
 }
+
+#ifndef PBH_F64
+// PBH_ROW_PHASE=0 keeps the complex64-chirp row kernel for generated chirps too (A/B runs)
+static bool row_phase_enabled() {
+    static const bool on = [] { const char* e = getenv("PBH_ROW_PHASE"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+static int launch_rowp(RowpParams prm, hipStream_t st) {
+    int64_t tiles = (int64_t)prm.nchan * prm.N1;
+    if (tiles > row_grid()) tiles = row_grid();
+    if (prm.counter) HIPCHECK(hipMemsetAsync(prm.counter, 0, sizeof(unsigned), st));
+    return launch_tile_kernel(k_rowp<kTilePoints, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+}
+#endif
 
 static int launch_small(int M, const SmallParams& prm, hipStream_t st, int64_t nseg = 1) {
     const int F = kTilePoints / M;
@@ -396,7 +422,14 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
             return colp ? launch_colq<OP_FWD_TW>(N1, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
         }});
-        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w};
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
+                     reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
+#ifndef PBH_F64
+        if (p->has_phase && row_phase_enabled()) {
+            RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(rpp, st); }});
+        } else
+#endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
@@ -424,7 +457,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         const int sb = 4, lo = block_lane_order();
         ColParams c1{in, work, inter, planar, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k, 0, p->N, 0};
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
-        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w};
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
+                     reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         ColParams c3{work, out, planar, inter, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k,
                      p->start, p->stop, p->start * S};
@@ -650,7 +684,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (!p) return PBH_OK;
     hipSetDevice(p->device);
     if (p->sub) pbh_plan_destroy(p->sub);
-    void* ptrs[] = {p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out,
+    void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -710,6 +744,15 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     HIPCHECK(hipMemcpyAsync(p->chan_freq, chan_freq_hz, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, coeff_hz, 1.0 / ((double)p->N * dt_s), 1.0 / ref_freq_hz,
                    p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
+    p->has_phase = false;
+#ifndef PBH_F64
+    // the fused row pass of multi-pass float32 plans reads the chirp as a phase (k_rowp)
+    if (p->N1 > 1 && p->N2 == kTilePoints && p->perm_w == 0 && !p->bsL) {
+        if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
+        cp.phase = p->chirp_phase;
+        p->has_phase = true;
+    }
+#endif
     hipLaunchKernelGGL(k_chirp, dim3(2048), dim3(256), 0, p->stream, cp);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));  // chan_freq_hz is a borrowed host buffer
@@ -732,6 +775,7 @@ int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
+    p->has_phase = false;  // a user-supplied chirp is applied as the complex64 values it is
     return PBH_OK;
 }
 
@@ -766,6 +810,7 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
+    p->has_phase = false;
     return PBH_OK;
 }
 
