@@ -3,11 +3,12 @@ passes, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts half of a
 read on gfx950 -> x2; WRITE_SIZE exact; both in KiB)."""
 import csv, glob, json, os, sys, collections
 root, out = sys.argv[1], sys.argv[2]
-NAMES = {"k_row": "k_row_fused", "k_deinterleave": "k_deinterleave", "k_reinterleave": "k_reinterleave",
+NAMES = {"k_rowp": "k_row_fused", "k_row": "k_row_fused", "k_deinterleave": "k_deinterleave", "k_reinterleave": "k_reinterleave",
          "k_small": "k_small"}
 def step(kname):
-    k = kname.replace("void pbh::", "").replace("pbh::", "")
-    if k.startswith("k_col<"):
+    import re as _re
+    k = _re.sub(r"(void )?pbh(32|64)?::", "", kname)
+    if k.startswith("k_col<") or k.startswith("k_colq<"):
         return "k_col_inv" if k.split(",")[1].strip().startswith("1") else "k_col_fwd"
     for a, b in NAMES.items():
         if k.startswith(a):

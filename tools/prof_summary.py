@@ -3,7 +3,8 @@ import csv, glob, os, sys, collections
 root = sys.argv[1]
 def short(n):
     n = n.split('(')[0]
-    return n.replace('void pbh::', '').replace('pbh::', '')
+    import re as _re
+    return _re.sub(r'(void )?pbh(32|64)?::', '', n)
 # kernel trace
 for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True):
     d = collections.defaultdict(list)
