@@ -145,6 +145,20 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
  * in : (nsample, nchan, npol) c64;  out: (crop_stop-crop_start, nchan, npol) c64.                   */
 int pbh_dedisperse(pbh_plan* plan, const void* in_c64, void* out_c64, int in_loc, int out_loc);
 
+/* The same transform on device-resident arrays whose memory layout is stated explicitly.  The
+ * reference's Signal.data is duck-typed (core.py:59-97) and numpy arrays carry strides, so a
+ * (nsample, nchan, npol) array need not be C-contiguous:
+ *   PBH_LAYOUT_SAMPLE_MAJOR  C-contiguous (nsample, nchan, npol); pitch ignored
+ *   PBH_LAYOUT_SERIES_MAJOR  time fastest: element (t, chan, pol) at base + (chan*npol + pol)*pitch + t,
+ *                            i.e. strides (1, npol*pitch, pitch) in elements, pitch >= the time length
+ * With a series-major end the layout pass at that end disappears (5 kernels -> 4 or 3).  For full-line
+ * stores pick out_dev and out_pitch so that (out_dev - crop_start*elem) and out_pitch*elem are multiples
+ * of 128 bytes (pulsarbat_amd.DeviceArray.empty_series_major does).  Multi-pass power-of-two plans only
+ * (PBH_ERR_UNSUPPORTED otherwise); asynchronous on the plan's stream.                                 */
+typedef enum { PBH_LAYOUT_SAMPLE_MAJOR = 0, PBH_LAYOUT_SERIES_MAJOR = 1 } pbh_layout;
+int pbh_dedisperse_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
+                          int out_layout, int64_t out_pitch);
+
 /* Same, followed by detection (core.py:766-774 / 930-966) and an nscrunch-fold sum over time of the
  * cropped samples (tail dropped): out is float32 (nout, nchan[, npol|4]), nout = (stop-start)/nscrunch. */
 int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int nscrunch, int mode,

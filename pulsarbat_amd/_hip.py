@@ -72,6 +72,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_int64)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
+    "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
@@ -235,6 +236,12 @@ class Plan:
         _check(lib().pbh_chirp_download(self._h, ptr, loc))
         return out
 
+    @property
+    def supports_series_major(self):
+        """True when pbh_dedisperse_layout accepts series-major ends for this plan."""
+        n = self.nsample
+        return (n & (n - 1)) == 0 and self.info["n1"] > 1
+
     def _check_in(self, x):
         if tuple(x.shape[:1]) != (self.nsample,) or int(np.prod(x.shape[1:])) != self.nchan * self.npol:
             raise ValueError(f"input shape {tuple(x.shape)} does not match plan "
@@ -242,12 +249,41 @@ class Plan:
         if x.dtype != self.dtype:
             raise TypeError(f"input must be {self.dtype} for this plan")
 
-    def dedisperse(self, x, out=None):
-        """x: (nsample, nchan, npol) c64 numpy or DeviceArray -> (stop-start, ...) same container."""
+    def dedisperse(self, x, out=None, out_layout=None):
+        """x: (nsample, nchan, npol) c64 numpy or DeviceArray -> (stop-start, ...) same container.
+
+        A DeviceArray may be stored series-major (time fastest, ``DeviceArray.series_major_pitch``);
+        the result then is too unless ``out_layout`` ("sample" | "series") says otherwise, and the
+        layout passes at the series-major ends are skipped (``pbh_dedisperse_layout``)."""
         from .device import DeviceArray
         self._check_in(x)
         self._sync_stream()
         oshape = (self.nout,) + tuple(x.shape[1:])
+        if isinstance(x, DeviceArray):
+            in_pitch = None if x.tensor.is_contiguous() else x.series_major_pitch()
+            if in_pitch is None and not x.tensor.is_contiguous():
+                raise ValueError("device input must be C-contiguous or series-major; call .contiguous()")
+            if out is not None:
+                out_pitch = None if out.tensor.is_contiguous() else out.series_major_pitch()
+                if out_pitch is None and not out.tensor.is_contiguous():
+                    raise ValueError("device output must be C-contiguous or series-major")
+            else:
+                want = out_layout if out_layout is not None else ("series" if in_pitch is not None else "sample")
+                if want not in ("sample", "series"):
+                    raise ValueError("out_layout must be 'sample' or 'series'")
+                if want == "series":
+                    out = DeviceArray.empty_series_major(oshape, self.dtype, device=self.device, align_start=self.crop_start)
+                    out_pitch = out.series_major_pitch()
+                else:
+                    out = DeviceArray.empty(oshape, self.dtype, device=self.device)
+                    out_pitch = None
+            if in_pitch is not None or out_pitch is not None:
+                if tuple(out.shape) != oshape or out.dtype != self.dtype:
+                    raise ValueError("output array does not match the plan")
+                _check(lib().pbh_dedisperse_layout(self._h, C.c_void_p(x.raw_ptr()), int(in_pitch is not None),
+                                                   int(in_pitch or 0), C.c_void_p(out.raw_ptr()),
+                                                   int(out_pitch is not None), int(out_pitch or 0)))
+                return out
         if out is None:
             if isinstance(x, DeviceArray):
                 out = DeviceArray.empty(oshape, self.dtype, device=self.device)

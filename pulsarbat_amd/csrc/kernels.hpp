@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kTilePoints / R, XS ? (2 * kTilePoints / R) / 256 :
 // walked tiles with a static stride was SLOWER than one-tile workgroups (1.11 vs 0.98 ms); the two
 // things that made the persistent form win are in k_colq's header below.
 struct ColpParams {
-    cf* data;          // planar work buffer: series s at s * plane, row r at r * N2
+    cf* data;          // planar work buffer: series s at s * plane, row r at r * N2 (stores; loads too unless ld set)
     int64_t plane;
     int S, N2;
     BigTwiddle tw;     // W_N, N = M * N2
@@ -168,6 +168,12 @@ struct ColpParams {
     int64_t crop_start, crop_stop;  // OP_TW_INV: keep time index t in [start, stop), t = row*N2 + n2
     int order;         // tile order: 0 = column groups of one series consecutive, 1 = series fastest
     unsigned* counter; // k_colq: dynamic tile hand-out (zeroed before the launch); null = static stride
+    // series-major device I/O (pbh_dedisperse_layout): loads may come from a different planar array
+    // (the caller's input, pitch ld_plane) and stores may go to one (the caller's output, pitch
+    // `plane`, time index shifted by st_shift = crop_start so that sample `start` lands at element 0)
+    const cf* ld = nullptr;
+    int64_t ld_plane = 0;
+    int64_t st_shift = 0;
 };
 
 // ---- persistent column pass with deferred, interleaved stores --------------------------------------
@@ -202,9 +208,15 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
 
     auto group_of = [&](uint32_t t) -> int { return p.order ? (int)(t / (uint32_t)p.S) : (int)(t % ngrp); };
     auto series_of = [&](uint32_t t) -> int { return p.order ? (int)(t % (uint32_t)p.S) : (int)(t / ngrp); };
-    auto tile_rsrc = [&](uint32_t t) {
-        return t < ntile ? make_rsrc(p.data + (int64_t)series_of(t) * p.plane + (int64_t)group_of(t) * F, tile_bytes)
+    const cf* ldb = p.ld ? p.ld : p.data;
+    const int64_t ldp = p.ld ? p.ld_plane : p.plane;
+    auto tile_rsrc = [&](uint32_t t) {   // where tile t is loaded from
+        return t < ntile ? make_rsrc(ldb + (int64_t)series_of(t) * ldp + (int64_t)group_of(t) * F, tile_bytes)
                          : make_rsrc(p.data, 0);
+    };
+    auto store_rsrc = [&](uint32_t t) {  // where its outputs go (the base may lie before the array when the
+                                         // first columns are cropped: only in-range offsets are ever used)
+        return make_rsrc(p.data + (int64_t)series_of(t) * p.plane + (int64_t)group_of(t) * F - p.st_shift, tile_bytes);
     };
     auto load_tables = [&](int n2, double2& bh, double2& bl, double2& sh, double2& sl) {
         const int64_t pb = ((int64_t)n2 * tau) & p.tw.mask, ps = ((int64_t)n2 * MR) & p.tw.mask;
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
                 z = zmul(z, zs);
             }
         }
-        rdo = rd;
+        rdo = store_rsrc(t);
         tto = (uint32_t)tau * (uint32_t)p.N2 + (uint32_t)n2;
         if (!more) break;
 #pragma unroll

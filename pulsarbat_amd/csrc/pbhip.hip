@@ -23,6 +23,7 @@
 #define pbh_decimate2 PBH_FN(decimate2)
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_dedisperse PBH_FN(dedisperse)
+#define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
 #define pbh_detect PBH_FN(detect)
@@ -366,7 +367,14 @@ struct DetectTail {
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 
-static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail()) {
+// device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major
+struct IoLayout {
+    int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
+    int64_t in_pitch = 0, out_pitch = 0;
+};
+
+static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
+                                     IoLayout io = IoLayout()) {
     std::vector<Step> steps;
     const int S = p->S;
     if (p->bsL) {
@@ -410,15 +418,21 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     const int N1 = p->N1, N2 = p->N2;
     cf* work = p->work;
 
-    if (variant == PBH_VARIANT_PLANAR5) {
+    const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
+    if (variant == PBH_VARIANT_PLANAR5 || in_sm || out_sm) {
         const int64_t N = p->N, start = p->start, stop = p->stop;
-        steps.push_back({"k_deinterleave", [=](hipStream_t st) {
-            return launch_deinterleave(in, work, N, S, st);
-        }});
+        if (!in_sm)
+            steps.push_back({"k_deinterleave", [=](hipStream_t st) {
+                return launch_deinterleave(in, work, N, S, st);
+            }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
-        const bool colp = colp_mode() != 0 && N2 % (kTilePoints / N1) == 0 && N < (1LL << 31);
+        const bool colp = (colp_mode() != 0 || in_sm || out_sm) && N2 % (kTilePoints / N1) == 0 && N < (1LL << 31);
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
+        if (in_sm) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
+            cp1.ld = in;
+            cp1.ld_plane = io.in_pitch;
+        }
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
             return colp ? launch_colq<OP_FWD_TW>(N1, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
         }});
@@ -434,6 +448,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
         ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
+        if (out_sm && !tail.out) {   // pass 3 writes the caller's series-major output directly, cropped
+            cp3.ld = work;
+            cp3.ld_plane = N;
+            cp3.data = out;
+            cp3.plane = io.out_pitch;
+            cp3.st_shift = start;
+        }
         steps.push_back({"k_col_inv", [=](hipStream_t st) {
             return colp ? launch_colq<OP_TW_INV>(N1, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
@@ -447,7 +468,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 HIPCHECK(hipGetLastError());
                 return (int)PBH_OK;
             }});
-        } else {
+        } else if (!out_sm) {
             steps.push_back({"k_reinterleave", [=](hipStream_t st) {
                 return launch_reinterleave(work, out, start, stop, S, N, st);
             }});
@@ -995,6 +1016,31 @@ int pbh_dedisperse(pbh_plan* p, const void* in_c64, void* out_c64, int in_loc, i
     if (out_loc == PBH_HOST && out_bytes)
         HIPCHECK(hipMemcpyAsync(out_c64, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
+    return PBH_OK;
+}
+
+// Device-resident dedispersion with explicit layouts at both ends (include/pbhip.h).
+int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
+                          int out_layout, int64_t out_pitch) {
+    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    auto bad = [](int l) { return l != PBH_LAYOUT_SAMPLE_MAJOR && l != PBH_LAYOUT_SERIES_MAJOR; };
+    if (bad(in_layout) || bad(out_layout)) return fail(PBH_ERR_INVALID, "bad layout");
+    const int64_t nout = p->stop - p->start;
+    if (in_layout == PBH_LAYOUT_SERIES_MAJOR && in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
+    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nout) return fail(PBH_ERR_INVALID, "out_pitch < output length");
+    HIPCHECK(hipSetDevice(p->device));
+    if (nout <= 0) return PBH_OK;
+    const bool any_sm = in_layout == PBH_LAYOUT_SERIES_MAJOR || out_layout == PBH_LAYOUT_SERIES_MAJOR;
+    if (any_sm && (p->bsL || p->N1 == 1 || p->N2 % (kTilePoints / p->N1) != 0 || p->N >= (1LL << 31)))
+        return fail(PBH_ERR_UNSUPPORTED, "series-major I/O needs a multi-pass power-of-two plan (nsample > one tile)");
+    IoLayout io;
+    io.in_layout = in_layout;
+    io.out_layout = out_layout;
+    io.in_pitch = in_pitch;
+    io.out_pitch = out_pitch;
+    auto steps = build_steps(p, (const cf*)in_dev, (cf*)out_dev, DetectTail(), io);
+    PBHCHECK(run_steps(steps, p->stream));
     return PBH_OK;
 }
 

@@ -42,6 +42,61 @@ class DeviceArray:
         return cls(torch.empty(tuple(int(s) for s in shape), dtype=_maps()[np.dtype(dtype)], device=dev))
 
     @classmethod
+    def empty_series_major(cls, shape, dtype, device=None, align_start=0):
+        """Uninitialised (n, ...) array stored series-major ("planar"): time is the fastest axis,
+        element (t, i, j, ...) lives at ``off + series*pitch + t``; strides ``(1, ..., pitch)``.
+
+        This is the layout the column passes work in, so a device-resident pipeline that keeps its
+        arrays this way skips both layout passes of ``coherent_dedispersion`` (C ABI:
+        ``pbh_dedisperse_layout``).  ``pitch`` is padded to a multiple of 16 elements and the storage
+        offset is ``align_start % 16`` so that sample ``align_start`` of the PRODUCER's time axis
+        falls on a 128-byte line (full-line stores for a cropped output)."""
+        import torch
+        shape = tuple(int(s) for s in shape)
+        n, rest = shape[0], shape[1:]
+        nser = int(np.prod(rest)) if rest else 1
+        off = int(align_start) % 16
+        pitch = -(-(n + off) // 16) * 16
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        flat = torch.empty(nser * pitch + 16, dtype=_maps()[np.dtype(dtype)], device=dev)
+        strides = [1]
+        acc = pitch
+        for d in reversed(rest):
+            strides.insert(1, acc)
+            acc *= d
+        return cls(flat.as_strided(shape, tuple(strides), off))
+
+    def series_major_pitch(self):
+        """Pitch (elements between consecutive series) if this array is stored series-major, else None."""
+        t = self._t
+        if t.dim() < 2 or t.shape[0] < 1:
+            return None
+        st = t.stride()
+        if t.shape[0] > 1 and st[0] != 1:
+            return None
+        pitch = st[-1]
+        if pitch < t.shape[0]:
+            return None
+        acc = pitch
+        for d in range(t.dim() - 1, 0, -1):
+            if t.shape[d] > 1 and st[d] != acc:
+                return None
+            acc *= t.shape[d]
+        return int(pitch)
+
+    def to_series_major(self, align_start=0):
+        """Copy into series-major storage (one transposing copy); a no-op if already stored that way."""
+        if self.series_major_pitch() is not None and not self._t.is_contiguous():
+            return self
+        out = DeviceArray.empty_series_major(self.shape, self.dtype, device=self.device_index, align_start=align_start)
+        out._t.copy_(self._t)
+        return out
+
+    def raw_ptr(self):
+        """Device pointer of element [0, 0, ...] whatever the strides."""
+        return self._t.data_ptr()
+
+    @classmethod
     def from_host(cls, a, device=None):
         import torch
         if isinstance(a, DeviceArray):

@@ -176,7 +176,7 @@ def _as_2d_chirp(chirp, z):
     return np.ascontiguousarray(np.asarray(chirp).reshape(want), dtype=np.complex64)
 
 
-def _prepare(z, DM, ref_freq, chirp, variant):
+def _prepare(z, DM, ref_freq, chirp, variant, allow_series=False):
     if not isinstance(z, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
     if ref_freq is None:
@@ -185,7 +185,14 @@ def _prepare(z, DM, ref_freq, chirp, variant):
     start, stop = _crop_bounds(z, DM, ref_freq)
     c2 = None if chirp is None else _as_2d_chirp(chirp, z)
     plan, on_device = _plan_for(z, DM, ref_freq, (start, stop), chirp=c2, variant=variant)
-    x = z.data.contiguous() if on_device else np.ascontiguousarray(z.data)
+    if on_device:
+        # a series-major (time-fastest) device array goes through as it is when the plan has the
+        # layout-aware path (multi-pass power-of-two lengths); otherwise one contiguous copy
+        keep = (allow_series and not z.data.tensor.is_contiguous() and z.data.series_major_pitch() is not None
+                and plan.supports_series_major)
+        x = z.data if keep else z.data.contiguous()
+    else:
+        x = np.ascontiguousarray(z.data)
     return plan, x, start, stop
 
 
@@ -204,8 +211,10 @@ def coherent_dedispersion(z, DM, /, *, ref_freq=None, chirp=None, variant="auto"
     unchecked, as in the reference.  The output is cropped to ``[start, stop)`` to drop
     wrap-around, and ``start_time`` advances by ``start / sample_rate``.  ``variant`` is a
     build-specific knob selecting the kernel sequence ("auto", "direct3", "planar5").
+    A DeviceArray stored series-major (``DeviceArray.to_series_major``) stays that way: input and
+    output skip their layout passes.
     """
-    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant)
+    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant, allow_series=True)
     y = plan.dedisperse(x)
     return type(z).like(z, y, **_advance(z, start))
 

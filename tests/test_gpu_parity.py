@@ -453,3 +453,47 @@ def test_fft_dispatch_any_length(n, batch, dtype):
         assert np.linalg.norm(np.asarray(got) - want) / np.linalg.norm(want) < tol
     back = pb.fft.ifft(pb.fft.fft(d, axis=0), axis=0)
     assert np.linalg.norm(np.asarray(back) - x) / np.linalg.norm(x) < 2 * tol
+
+
+# ---- series-major (time-fastest) device arrays: layout passes skipped (pbh_dedisperse_layout) --------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dm,dtype", [((1 << 16, 4, 2), 20.0, np.complex64), ((1 << 18, 3, 2), 30.0, np.complex64),
+                                            ((1 << 17, 5), 10.0, np.complex64), ((1 << 16, 2, 2), 20.0, np.complex128)])
+def test_series_major_io(shape, dm, dtype):
+    rng = np.random.default_rng(11)
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(dtype)
+    z = make_signal(x, 1e6, 1e9, start_time=pb.Time(56000.0, format="mjd"))
+    yr, start, stop = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    tol = RTOL_L2 if dtype == np.complex64 else RTOL_F64
+    zd = z.to_device()
+    zs = type(z).like(z, zd.data.to_series_major())
+    assert zs.data.series_major_pitch() is not None and not zs.data.tensor.is_contiguous()
+    assert np.array_equal(np.asarray(zs.data), x)
+    # series-major in -> series-major out
+    y = pb.coherent_dedispersion(zs, pb.DM(dm))
+    assert y.shape == yr.shape and y.data.series_major_pitch() is not None
+    assert series_errors(y, yr)[0] < tol
+    assert abs((y.start_time - z.start_time).to_value(u.s) - start / 1e6) < 1e-12
+    # mixed ends through the plan
+    from pulsarbat_amd.transforms.dedispersion import _prepare
+    plan, xin, _, _ = _prepare(zs, pb.DM(dm), None, None, "auto", allow_series=True)
+    y2 = plan.dedisperse(xin, out_layout="sample")
+    assert y2.tensor.is_contiguous() and series_errors(y2, yr)[0] < tol
+    y3 = plan.dedisperse(zd.data, out_layout="series")
+    assert y3.series_major_pitch() is not None and series_errors(y3, yr)[0] < tol
+    # bit-identical to the sample-major path (same kernels in the middle, same arithmetic)
+    y0 = plan.dedisperse(zd.data)
+    assert np.array_equal(np.asarray(y0), np.asarray(y3))
+
+
+@pytest.mark.gpu
+def test_series_major_fallback_small_and_bluestein():
+    """Lengths without the layout-aware path (one tile, Bluestein) take one contiguous copy instead."""
+    rng = np.random.default_rng(12)
+    for n in (4096, 30000):
+        x = (rng.standard_normal((n, 2, 2)) + 1j * rng.standard_normal((n, 2, 2))).astype(np.complex64)
+        z = make_signal(x, 1e6, 1e9)
+        zs = type(z).like(z, z.to_device().data.to_series_major())
+        y = pb.coherent_dedispersion(zs, pb.DM(5.0))
+        yr, _, _ = orc.coherent_dedispersion(x, 5.0, 1e6, 1e9)
+        assert series_errors(y, yr)[0] < RTOL_L2
