@@ -411,10 +411,19 @@ __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
     x.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return x.c;
 }
+// gfx950 hazard LLVM does not cover (found with tools/stress_c128.py): a buffer store of more than
+// 64 bits per lane WITH an SGPR offset, directly followed by a VALU write of its data registers
+// (`buffer_store_dwordx4 v[92:95], ..., s63 offen` then `v_fma_f64 v[94:95], ...`), stores stale data
+// in 4 of every 16 lanes.  The hazard recognizer only guards the no-soffset form.  Every complex128
+// store therefore carries its own wait states, and nothing is scheduled across them.
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     union { u32x4 u; cf c; } x;
     x.c = a;
     __builtin_amdgcn_raw_buffer_store_b128(x.u, r, voff, soff, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 3");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 #else
 __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {

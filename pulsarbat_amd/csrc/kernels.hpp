@@ -18,6 +18,7 @@
 namespace PBH_NS {
 
 enum ColOp { OP_FWD_TW = 0, OP_TW_INV = 1 };
+
 enum Layout { LAYOUT_INTERLEAVED = 0, LAYOUT_PLANAR = 1, LAYOUT_BLOCK = 2 };
 
 // Column addressing.  A "column" is one (n2, series) pair; element (row, n2, s):
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
                         __builtin_amdgcn_sched_barrier(0x38E);
 #pragma unroll
                         for (int u = 0; u < R / NBL; ++u) buf_store(rd, voff, (q + u * NBL) * STEP, v[q + u * NBL]);
-                        __builtin_amdgcn_sched_barrier(0x38E);
+                            __builtin_amdgcn_sched_barrier(0x38E);
                     }
                 };
                 fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, f * M, w, hk);

@@ -371,7 +371,9 @@ def check128(shape, dm, sr=1e6, fc=1e9, seed=2, variant="auto", device=False):
 
 @pytest.mark.parametrize("shape,dm", [((16, 2), 0.001), ((4096, 4, 2), 5.0), ((8192, 4), 50.0), ((1 << 13, 3, 2), 10.0),
                                       ((1 << 14, 2, 2), 10.0), ((1 << 16, 2, 2), 20.0), ((1 << 18, 2), 20.0),
-                                      ((1 << 20, 1, 2), 40.0)])
+                                      ((1 << 20, 1, 2), 40.0),
+                                      # two row tiles per workgroup: the case that exposed the gfx950 wide-store hazard
+                                      ((1 << 20, 2, 2), 40.0), ((1 << 19, 4, 2), 25.0)])
 def test_c128_parity(shape, dm):
     check128(shape, dm)
 
@@ -497,3 +499,24 @@ def test_series_major_fallback_small_and_bluestein():
         y = pb.coherent_dedispersion(zs, pb.DM(5.0))
         yr, _, _ = orc.coherent_dedispersion(x, 5.0, 1e6, 1e9)
         assert series_errors(y, yr)[0] < RTOL_L2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,shape,dm", [(np.complex128, (1 << 20, 2, 2), 40.0), (np.complex64, (1 << 21, 4, 2), 30.0)])
+def test_repeatable_bit_for_bit(dtype, shape, dm):
+    """The same call gives the same bits every time (tile hand-out order, prefetch timing and pinned stores
+    must not leak into the results); persistent loops run several tiles per workgroup at these sizes."""
+    rng = np.random.default_rng(2)
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(dtype)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    ref = {}
+    for it in range(6):
+        for variant in ("planar5", "direct3"):
+            y = np.asarray(pb.coherent_dedispersion(z, pb.DM(dm), variant=variant))
+            if variant in ref:
+                assert np.array_equal(y, ref[variant]), f"{variant}: repeat {it} differs from the first run"
+            else:
+                ref[variant] = y
+    yr, _, _ = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    for variant, y in ref.items():
+        assert series_errors(y, yr)[0] < (RTOL_L2 if dtype == np.complex64 else RTOL_F64)
