@@ -96,8 +96,14 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    t_start = time.perf_counter()
+
+    def mark(what):  # wall-clock trail on stderr: where a slow launch spends its time (imports, RCCL init, ...)
+        log(f"[bench +{time.perf_counter() - t_start:7.1f}s] {what}")
+
     import torch
     import torch.distributed as dist
+    mark("torch imported")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +116,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        mark("process group ready")
 
     from pulsarbat_amd import _hip
     from pulsarbat_amd.device import DeviceArray
@@ -142,6 +149,7 @@ def main():
     plan.chirp_generate(coeff, 1.0 / sr, freqs, CENTER_HZ)
     torch.cuda.synchronize()
     chirp_ms = (time.perf_counter() - t0) * 1e3
+    mark("plan + chirp ready")
 
     def barrier():
         if distributed:
@@ -151,11 +159,13 @@ def main():
     for _ in range(args.warmup):
         plan.dedisperse(x, out=y)
     barrier()
+    mark("warm-up done (first barrier includes RCCL communicator set-up)")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         plan.dedisperse(x, out=y)
     barrier()
     elapsed = time.perf_counter() - t0
+    mark("timed region done")
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -234,6 +244,7 @@ def main():
                 result["cpu_baseline"] = cpu_baseline()
             except Exception as exc:  # the baseline is a reported extra; never lose the GPU line
                 result["cpu_baseline"] = {"error": repr(exc)}
+        mark("extras done")
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:
         dist.barrier()

@@ -158,6 +158,10 @@ int pbh_dedisperse(pbh_plan* plan, const void* in_c64, void* out_c64, int in_loc
 typedef enum { PBH_LAYOUT_SAMPLE_MAJOR = 0, PBH_LAYOUT_SERIES_MAJOR = 1 } pbh_layout;
 int pbh_dedisperse_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
                           int out_layout, int64_t out_pitch);
+/* pbh_dedisperse_detect (below) for a device-resident input with a stated layout; out is the C-contiguous
+ * detected array.  A series-major input needs the fused tail (nscrunch % 64 == 0): 4 kernels.            */
+int pbh_dedisperse_detect_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch,
+                                 void* out_f32_dev, int nscrunch, int mode);
 
 /* Same, followed by detection (core.py:766-774 / 930-966) and an nscrunch-fold sum over time of the
  * cropped samples (tail dropped): out is float32 (nout, nchan[, npol|4]), nout = (stop-start)/nscrunch. */

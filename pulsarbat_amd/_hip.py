@@ -73,6 +73,7 @@ SIGNATURES = {
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
+    "pbh_dedisperse_detect_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
@@ -306,6 +307,13 @@ class Plan:
                 out = DeviceArray.empty(oshape, self.real_dtype, device=self.device)
             else:
                 out = np.empty(oshape, dtype=self.real_dtype)
+        if isinstance(x, DeviceArray) and not x.tensor.is_contiguous():
+            pitch = x.series_major_pitch()
+            if pitch is None:
+                raise ValueError("device input must be C-contiguous or series-major; call .contiguous()")
+            _check(lib().pbh_dedisperse_detect_layout(self._h, C.c_void_p(x.raw_ptr()), 1, int(pitch),
+                                                      C.c_void_p(out.data_ptr()), int(nscrunch), m))
+            return out
         pin, lin = _ptr_loc(x)
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))

@@ -24,6 +24,7 @@
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
+#define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
 #define pbh_detect PBH_FN(detect)
@@ -249,28 +250,32 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
 #ifndef PBH_F64
     if (prm.perm_w == 8) return launch_tile_kernel(k_row2<true>, prm, tiles, 512, st);
 #endif
-    // PBH_ROW_SPREAD: 0 = three bursts, 1 = per stage, 2 = per tick (pinned), 3 (default) = per tick + tiles
-    // handed out by an atomic counter.  Config 2: 1.16 / 1.14 / 1.11 / 1.085 ms.
+    // Product kernel: memory instructions pinned to the butterflies' ticks, tiles handed out by an atomic
+    // counter.  PBH_ROW_SPREAD=2 keeps the ticks but walks tiles with a static stride; the older forms
+    // (0 = three bursts, 1 = per stage) exist in -DPBH_DIAGNOSTIC builds only, for the A/B numbers of
+    // DESIGN.md 6 (config 2: 1.16 / 1.14 / 1.11 / 1.085 ms).
     static const int spread = [] { const char* e = getenv("PBH_ROW_SPREAD"); return e ? atoi(e) : 3; }();
-    if (spread >= 2) {
-        RowParams q = prm;
-        if (spread == 2) q.counter = nullptr;
-        if (q.counter) HIPCHECK(hipMemsetAsync(q.counter, 0, sizeof(unsigned), st));
-        switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 2>, q, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
-            FOR_ROW_M(X)
-#undef X
-        }
-    }
-    if (spread) {
+#ifdef PBH_DIAGNOSTIC
+    if (spread == 1) {
         switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 1>, prm, tiles, kTilePoints / PBH_R, st);
             FOR_ROW_M(X)
 #undef X
         }
     }
-    switch (M) {
+    if (spread == 0) {
+        switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st);
+            FOR_ROW_M(X)
+#undef X
+        }
+    }
+#endif
+    RowParams q = prm;
+    if (spread == 2) q.counter = nullptr;
+    if (q.counter) HIPCHECK(hipMemsetAsync(q.counter, 0, sizeof(unsigned), st));
+    switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 2>, q, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)
 #undef X
     }
@@ -1145,6 +1150,39 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     if (out_loc == PBH_HOST && out_bytes)
         HIPCHECK(hipMemcpyAsync(out_f32, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
+    return PBH_OK;
+}
+
+// pbh_dedisperse_detect for a device-resident input with a stated layout (series-major inputs skip the
+// de-interleave pass; the fused detect tail already reads the planar workspace): 4 kernels.
+int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
+                                 int nscrunch, int mode) {
+    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nscrunch <= 0) return fail(PBH_ERR_INVALID, "nscrunch must be positive");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    if (in_layout != PBH_LAYOUT_SAMPLE_MAJOR && in_layout != PBH_LAYOUT_SERIES_MAJOR) return fail(PBH_ERR_INVALID, "bad layout");
+    const int oe = detect_out_elems(mode, p->npol);
+    if (!oe) return fail(PBH_ERR_INVALID, "bad detect mode");
+    if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
+    if (in_layout == PBH_LAYOUT_SERIES_MAJOR) {
+        if (in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
+        if (p->bsL || p->N1 == 1 || p->N2 % (kTilePoints / p->N1) != 0 || p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
+            p->nchan > 65535)
+            return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan and nscrunch % 64 == 0");
+    } else {
+        return pbh_dedisperse_detect(p, in_dev, out_dev, nscrunch, mode, PBH_DEVICE, PBH_DEVICE);
+    }
+    HIPCHECK(hipSetDevice(p->device));
+    if ((p->stop - p->start) / nscrunch <= 0) return PBH_OK;
+    DetectTail tail;
+    tail.out = (real*)out_dev;
+    tail.mode = mode;
+    tail.nscrunch = nscrunch;
+    IoLayout io;
+    io.in_layout = in_layout;
+    io.in_pitch = in_pitch;
+    auto steps = build_steps(p, (const cf*)in_dev, nullptr, tail, io);
+    PBHCHECK(run_steps(steps, p->stream));
     return PBH_OK;
 }
 

@@ -24,6 +24,7 @@
     int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
+    int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
     int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
@@ -140,6 +141,9 @@ int pbh_dedisperse(pbh_plan* p, const void* in, void* out, int il, int ol) {
 }
 int pbh_dedisperse_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ol, int64_t op) {
     FORWARD(p, pbh32_dedisperse_layout(P32(p), in, il, ip, out, ol, op), pbh64_dedisperse_layout(P64(p), in, il, ip, out, ol, op));
+}
+int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ns, int mode) {
+    FORWARD(p, pbh32_dedisperse_detect_layout(P32(p), in, il, ip, out, ns, mode), pbh64_dedisperse_detect_layout(P64(p), in, il, ip, out, ns, mode));
 }
 int pbh_dedisperse_detect(pbh_plan* p, const void* in, void* out, int ns, int mode, int il, int ol) {
     FORWARD(p, pbh32_dedisperse_detect(P32(p), in, out, ns, mode, il, ol), pbh64_dedisperse_detect(P64(p), in, out, ns, mode, il, ol));

@@ -228,7 +228,8 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     scrunch function; SURVEY.md 8a row 9 defines it.  Returns a float32 array (numpy or
     DeviceArray) and the crop start, not a Signal, since the sample rate changes.
     """
-    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant)
+    # a series-major device array goes through as it is when the fused tail applies (nscrunch % 64 == 0)
+    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant, allow_series=int(nscrunch) % 64 == 0)
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
 
 

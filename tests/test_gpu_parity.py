@@ -520,3 +520,18 @@ def test_repeatable_bit_for_bit(dtype, shape, dm):
     yr, _, _ = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
     for variant, y in ref.items():
         assert series_errors(y, yr)[0] < (RTOL_L2 if dtype == np.complex64 else RTOL_F64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,nscrunch", [("I", 64), ("linear", 128), ("intensity", 64), ("I", 16)])
+def test_series_major_dedisperse_detect(mode, nscrunch):
+    """dedisperse_detect on a series-major device array: same numbers as on the contiguous array."""
+    rng = np.random.default_rng(13)
+    shape = (1 << 17, 4, 2)
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(np.complex64)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    zs = type(z).like(z, z.data.to_series_major())
+    a, s0 = pb.dedisperse_detect(z, pb.DM(15.0), mode=mode, nscrunch=nscrunch)
+    b, s1 = pb.dedisperse_detect(zs, pb.DM(15.0), mode=mode, nscrunch=nscrunch)
+    assert s0 == s1 and a.shape == b.shape
+    assert np.array_equal(np.asarray(a), np.asarray(b))
