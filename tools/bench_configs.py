@@ -39,8 +39,16 @@ def config5(steps=10):
     for _ in range(steps):
         plan.dedisperse(x, out=y)
     torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / steps
+    xs = x.to_series_major()
+    for _ in range(3):
+        plan.dedisperse_detect(xs, nscrunch=1024, mode="I", out=out)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.dedisperse_detect(xs, nscrunch=1024, mode="I", out=out)
+    torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / steps
     ns = n * nchan * npol
-    return {"config": "configs[4] per-GPU share: 2^24 x 8 of 64 chan x 2 pol, DM 1000, Stokes-I + 1024x scrunch",
+    return {"ms_fused_detect_series_major_input": dt3 * 1e3, "Msamples_per_s_series_major_input": ns / dt3 / 1e6,
+            "config": "configs[4] per-GPU share: 2^24 x 8 of 64 chan x 2 pol, DM 1000, Stokes-I + 1024x scrunch",
             "crop": [start, stop], "out_shape": list(out.shape), "ms_fused_detect": dt * 1e3,
             "Msamples_per_s_fused": ns / dt / 1e6, "ms_voltage_output": dt2 * 1e3,
             "alg_bytes_per_sample": 60.0, "GBps_at_60B": 60.0 * ns / dt / 1e9}
