@@ -365,9 +365,11 @@ def detect(x, mode="intensity", nscrunch=1):
     else:
         oshape = (n // nscrunch, nchan, 4)
     if isinstance(x, DeviceArray):
+        x = x.contiguous()   # a strided (e.g. series-major) view costs one copy here
         out = DeviceArray.empty(oshape, rdt, device=x.device_index)
         dev, stream = x.device_index, _stream_ptr(x.device_index)
     else:
+        x = np.ascontiguousarray(x)
         out = np.empty(oshape, dtype=rdt)
         dev, stream = 0, C.c_void_p(0)
     pin, lin = _ptr_loc(x)
@@ -384,6 +386,7 @@ def fft_c2c(x, inverse=False):
     n = x.shape[0]
     batch = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
     if isinstance(x, DeviceArray):
+        x = x.contiguous()
         out = DeviceArray.empty(x.shape, x.dtype, device=x.device_index)
         dev, stream = x.device_index, _stream_ptr(x.device_index)
     else:
@@ -418,6 +421,7 @@ def zero_edges(x_dev, shift):
 def decimate2(y_dev):
     """out[m, s] = (-1)^m y[2m, s] for a device (n, s) complex array."""
     from .device import DeviceArray
+    y_dev = y_dev.contiguous()
     n, s = y_dev.shape[0], int(np.prod(y_dev.shape[1:]))
     nout = (n + 1) // 2
     out = DeviceArray.empty((nout,) + tuple(y_dev.shape[1:]), y_dev.dtype, device=y_dev.device_index)

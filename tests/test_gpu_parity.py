@@ -535,3 +535,19 @@ def test_series_major_dedisperse_detect(mode, nscrunch):
     b, s1 = pb.dedisperse_detect(zs, pb.DM(15.0), mode=mode, nscrunch=nscrunch)
     assert s0 == s1 and a.shape == b.shape
     assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
+def test_series_major_arrays_in_other_ops():
+    """A series-major device array is an ordinary (strided) array for everything else: detection, FFT,
+    slicing and host copies give the same numbers as the contiguous array."""
+    rng = np.random.default_rng(14)
+    x = (rng.standard_normal((4096, 3, 2)) + 1j * rng.standard_normal((4096, 3, 2))).astype(np.complex64)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    zs = type(z).like(z, z.data.to_series_major())
+    assert np.array_equal(np.asarray(zs.to_intensity().data), np.asarray(z.to_intensity().data))
+    assert np.array_equal(np.asarray(zs.to_stokes().data), np.asarray(z.to_stokes().data))
+    assert np.array_equal(np.asarray(pb.fft.fft(zs.data, axis=0)), np.asarray(pb.fft.fft(z.data, axis=0)))
+    part = zs[100:2148]
+    assert part.data.series_major_pitch() == zs.data.series_major_pitch()
+    assert np.array_equal(np.asarray(part.data), x[100:2148])
