@@ -290,6 +290,11 @@ def test_full_size_properties():
     err0 = (torch.linalg.vector_norm(y0.data.tensor - x1) / torch.linalg.vector_norm(x1)).item()
     assert y0.shape == (n, nchan, npol) and err0 < 2e-6, f"identity residual {err0:.2e}"
     del y0
+    # the series-major (time-fastest) device layout gives the same bits with two kernels fewer
+    zs = pb.DualPolarizationSignal(pb.DeviceArray(x1).to_series_major(), **kw)
+    ys = pb.coherent_dedispersion(zs, pb.DM(dm))
+    assert ys.data.series_major_pitch() is not None and torch.equal(ys.data.tensor, y1.data.tensor)
+    del zs, ys
     # one series against the oracle (1-D, 2^24: a few seconds of CPU)
     c, p = 5, 1
     xs = x1[:, c, p].cpu().numpy().reshape(-1, 1)
