@@ -140,6 +140,12 @@ int pbh_pol_basis(int device, void* hip_stream, int dtype, const void* in_dev, v
 int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
                    int unit_words, const int64_t* delay);
 
+/* Blocking copy between caller (host) memory and device memory, direction 0 = host->device, 1 =
+ * device->host, ordered on hip_stream.  Goes through the library's own pinned bounce buffers, like every
+ * PBH_HOST argument of the calls below: pageable caller memory is never handed to the HIP runtime, whose
+ * cache of on-the-fly pins can outlive the caller's allocation ("host transfers").           */
+int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_t bytes, int direction);
+
 /* ---- the hot path ----------------------------------------------------------------------------- */
 /* Replaces  x = ifft(fft(z.data, axis=0) * chirp, axis=0)[start:stop]  (dedispersion.py:125-133).
  * in : (nsample, nchan, npol) c64;  out: (crop_stop-crop_start, nchan, npol) c64.                   */

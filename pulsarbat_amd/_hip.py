@@ -72,6 +72,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_int64)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
+    "pbh_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_detect_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -153,6 +154,13 @@ def _ptr_loc(a):
             raise ValueError("host arrays must be C-contiguous")
         return C.c_void_p(a.ctypes.data), HOST
     raise TypeError(f"unsupported array type {type(a)!r}")
+
+
+def transfer(device, dst_ptr, src_ptr, nbytes, to_host):
+    """Blocking host<->device copy through the library's pinned bounce buffers (pbh_transfer)."""
+    _require_device()
+    _check(lib().pbh_transfer(int(device), _stream_ptr(int(device)), C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
+                              int(nbytes), 1 if to_host else 0))
 
 
 def _stream_ptr(device):

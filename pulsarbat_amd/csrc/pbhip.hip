@@ -22,6 +22,7 @@
 #define pbh_pol_basis PBH_FN(pol_basis)
 #define pbh_decimate2 PBH_FN(decimate2)
 #define pbh_incoherent PBH_FN(incoherent)
+#define pbh_transfer PBH_FN(transfer)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
@@ -117,6 +118,8 @@ static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
     if (e != hipSuccess)
         return fail(PBH_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
     if (p) p->owned_bytes += (int64_t)bytes;
+    static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;  // debugging aid: where the library's buffers are
+    if (trace) fprintf(stderr, "[pbhip] alloc %p .. %p (%zu bytes)\n", *ptr, (char*)*ptr + bytes, bytes);
     return PBH_OK;
 }
 
@@ -485,6 +488,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_col<OP_FWD_TW>(N1, c1, st); }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
                      reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
+#ifndef PBH_F64
+        if (p->has_phase && row_phase_enabled()) {
+            RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N),
+                           reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(rpp, st); }});
+        } else
+#endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
         ColParams c3{work, out, planar, inter, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k,
                      p->start, p->stop, p->start * S};
@@ -499,6 +509,99 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch) {
 
 static int run_steps(std::vector<Step>& steps, hipStream_t st) {
     for (auto& s : steps) PBHCHECK(s.launch(st));
+    return PBH_OK;
+}
+
+
+// ---- host <-> device transfers of caller memory --------------------------------------------------------------
+// Large copies between pageable caller memory and the device do NOT go to hipMemcpyAsync directly: the
+// runtime pins such ranges on the fly and keeps the pins in a cache, and a cached pin of host addresses
+// the caller's allocator has since recycled (glibc hands freed heap back and regrows it) made a later
+// device-to-host copy die with "Memory access fault ... Write access to a read-only page" -- one run
+// in ~15 of the GPU test suite, at a reproducible test.  The library therefore moves such data through
+// two pinned bounce buffers of its own (per thread and device), chunk by chunk, the CPU copy of one
+// chunk overlapping the DMA of the other.  Both functions return when the transfer is complete.
+// pbh_dedisperse_stream pins its buffers explicitly (hipHostRegister) for the duration of the call instead.
+namespace {
+constexpr size_t kBounceBytes = 8u << 20;
+constexpr size_t kBounceMin = 256u << 10;   // smaller copies: the runtime stages them itself, nothing is pinned
+struct Bounce {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+Bounce* bounce_for_current_device() {
+    static thread_local Bounce table[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Bounce& b = table[dev];
+    if (!b.buf[0]) {
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc(&b.buf[i], kBounceBytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&b.ev[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+        }
+    }
+    return &b;
+}
+}  // namespace
+
+static hipError_t xfer_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+    Bounce* b = bytes >= kBounceMin ? bounce_for_current_device() : nullptr;
+    if (!b) {
+        hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st);
+        return e == hipSuccess ? hipStreamSynchronize(st) : e;
+    }
+    hipError_t e = hipSuccess;
+    size_t off = 0;
+    for (int i = 0; off < bytes && e == hipSuccess; ++i, off += kBounceBytes) {
+        const int k = i & 1;
+        const size_t c = bytes - off < kBounceBytes ? bytes - off : kBounceBytes;
+        if (i >= 2) e = hipEventSynchronize(b->ev[k]);
+        if (e != hipSuccess) break;
+        memcpy(b->buf[k], (const char*)src_host + off, c);
+        e = hipMemcpyAsync((char*)dst_dev + off, b->buf[k], c, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(b->ev[k], st);
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    return e != hipSuccess ? e : e2;
+}
+
+static hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
+    Bounce* b = bytes >= kBounceMin ? bounce_for_current_device() : nullptr;
+    if (!b) {
+        hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipStreamSynchronize(st) : e;
+    }
+    hipError_t e = hipSuccess;
+    const size_t nchunk = (bytes + kBounceBytes - 1) / kBounceBytes;
+    auto len = [&](size_t i) { return bytes - i * kBounceBytes < kBounceBytes ? bytes - i * kBounceBytes : kBounceBytes; };
+    for (size_t i = 0; i <= nchunk && e == hipSuccess; ++i) {
+        if (i < nchunk) {   // request chunk i (its buffer was drained two rounds ago)
+            const int k = (int)(i & 1);
+            e = hipMemcpyAsync(b->buf[k], (const char*)src_dev + i * kBounceBytes, len(i), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(b->ev[k], st);
+        }
+        if (i >= 1 && e == hipSuccess) {   // drain chunk i-1 while chunk i is on the wire
+            const int k = (int)((i - 1) & 1);
+            e = hipEventSynchronize(b->ev[k]);
+            if (e == hipSuccess) memcpy((char*)dst_host + (i - 1) * kBounceBytes, b->buf[k], len(i - 1));
+        }
+    }
+    return e;
+}
+
+// Plain copy between caller (host) memory and device memory through the bounce buffers above; what
+// pulsarbat_amd.DeviceArray uses for from_host() / get() so that no pageable caller memory is ever
+// handed to the runtime by this package.  direction: 0 = host -> device, 1 = device -> host.  Blocking.
+int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_t bytes, int direction) {
+    if (bytes == 0) return PBH_OK;
+    if (!dst || !src) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (direction != 0 && direction != 1) return fail(PBH_ERR_INVALID, "bad direction");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHECK(direction == 0 ? xfer_h2d(dst, src, bytes, st) : xfer_d2h(dst, src, bytes, st));
     return PBH_OK;
 }
 
@@ -793,7 +896,7 @@ int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
     const float2* src = (const float2*)chirp_c64;
     if (loc == PBH_HOST) {
         PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, bytes));
-        HIPCHECK(hipMemcpyAsync(p->stage_in, chirp_c64, bytes, hipMemcpyHostToDevice, p->stream));
+        HIPCHECK(xfer_h2d(p->stage_in, chirp_c64, bytes, p->stream));
         src = (const float2*)p->stage_in;
     }
     hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, (float2*)nullptr,
@@ -819,7 +922,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
                        (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
-        HIPCHECK(hipMemcpyAsync(chirp_c64, dst, bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHECK(xfer_d2h(chirp_c64, dst, bytes, p->stream));
         HIPCHECK(hipStreamSynchronize(p->stream));
     }
     return PBH_OK;
@@ -979,7 +1082,7 @@ int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t ns
         hipLaunchKernelGGL(k_chirp, dim3(1024), dim3(256), 0, st, cp);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && loc == PBH_HOST) e = hipMemcpyAsync(chirp_c64, dbuf, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && loc == PBH_HOST) e = xfer_d2h(chirp_c64, dbuf, bytes, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_chirp_function: ") + hipGetErrorString(e));
@@ -996,7 +1099,7 @@ static int resolve_io(pbh_plan* p, const void* in, void* out, size_t out_bytes, 
     *dout = out;
     if (in_loc == PBH_HOST) {
         PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, in_bytes));
-        HIPCHECK(hipMemcpyAsync(p->stage_in, in, in_bytes, hipMemcpyHostToDevice, p->stream));
+        HIPCHECK(xfer_h2d(p->stage_in, in, in_bytes, p->stream));
         *din = (const cf*)p->stage_in;
     }
     if (out_loc == PBH_HOST) {
@@ -1019,7 +1122,7 @@ int pbh_dedisperse(pbh_plan* p, const void* in_c64, void* out_c64, int in_loc, i
         PBHCHECK(run_steps(steps, p->stream));
     }
     if (out_loc == PBH_HOST && out_bytes)
-        HIPCHECK(hipMemcpyAsync(out_c64, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHECK(xfer_d2h(out_c64, dout, out_bytes, p->stream));
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     return PBH_OK;
 }
@@ -1087,7 +1190,7 @@ int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const 
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &sin, in_bytes)) != PBH_OK) return rc;
-        hipMemcpyAsync(sin, in_c64, in_bytes, hipMemcpyHostToDevice, st);
+        xfer_h2d(sin, in_c64, in_bytes, st);
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
@@ -1100,7 +1203,7 @@ int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const 
     rc = launch_detect(st, din, dout, nout, nchan, npol, mode, nscrunch);
     hipError_t e = hipSuccess;
     if (rc == PBH_OK && out_loc == PBH_HOST && out_bytes)
-        e = hipMemcpyAsync(out_f32, dout, out_bytes, hipMemcpyDeviceToHost, st);
+        e = xfer_d2h(out_f32, dout, out_bytes, st);
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
@@ -1148,7 +1251,7 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
         PBHCHECK(rc);
     }
     if (out_loc == PBH_HOST && out_bytes)
-        HIPCHECK(hipMemcpyAsync(out_f32, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHECK(xfer_d2h(out_f32, dout, out_bytes, p->stream));
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     return PBH_OK;
 }
@@ -1261,7 +1364,7 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &sin, bytes));
-        hipMemcpyAsync(sin, in_c64, bytes, hipMemcpyHostToDevice, st);
+        xfer_h2d(sin, in_c64, bytes, st);
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
@@ -1278,7 +1381,7 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
         rc = fft_c2c_ring(device, st, din, dout, n, batch, inverse);
     }
     hipError_t e = hipSuccess;
-    if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out_c64, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (rc == PBH_OK && out_loc == PBH_HOST) e = xfer_d2h(out_c64, dout, bytes, st);
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
@@ -1308,7 +1411,7 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &stg_in, bytes));
-        hipMemcpyAsync(stg_in, in, bytes, hipMemcpyHostToDevice, st);
+        xfer_h2d(stg_in, in, bytes, st);
         din = (const cf*)stg_in;
     }
     if (out_loc == PBH_HOST) {
@@ -1373,7 +1476,7 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
         }
     }
     hipError_t e = hipSuccess;
-    if (rc == PBH_OK && out_loc == PBH_HOST) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (rc == PBH_OK && out_loc == PBH_HOST) e = xfer_d2h(out, dout, bytes, st);
     if (in_loc == PBH_HOST || out_loc == PBH_HOST) {
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;

@@ -22,6 +22,7 @@
     int P##zero_edges(int, void*, int, void*, int64_t, int, const double*);                                     \
     int P##pol_basis(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
+    int P##transfer(int, void*, void*, const void*, size_t, int);                                               \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
@@ -138,6 +139,9 @@ int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double
 }
 int pbh_dedisperse(pbh_plan* p, const void* in, void* out, int il, int ol) {
     FORWARD(p, pbh32_dedisperse(P32(p), in, out, il, ol), pbh64_dedisperse(P64(p), in, out, il, ol));
+}
+int pbh_transfer(int device, void* stream, void* dst, const void* src, size_t bytes, int direction) {
+    return done(PBH_C64, pbh32_transfer(device, stream, dst, src, bytes, direction));
 }
 int pbh_dedisperse_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ol, int64_t op) {
     FORWARD(p, pbh32_dedisperse_layout(P32(p), in, il, ip, out, ol, op), pbh64_dedisperse_layout(P64(p), in, il, ip, out, ol, op));

@@ -103,7 +103,14 @@ class DeviceArray:
             return a
         a = np.ascontiguousarray(a)
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
-        return cls(torch.from_numpy(a).to(dev))
+        if np.dtype(a.dtype) not in _maps() or a.size == 0:
+            return cls(torch.from_numpy(a).to(dev))
+        # through the library's pinned bounce buffers, not torch's copy: pageable numpy memory handed to
+        # the HIP runtime gets pinned on the fly and the pin is cached beyond the array's life
+        from . import _hip
+        t = torch.empty(a.shape, dtype=_maps()[np.dtype(a.dtype)], device=dev)
+        _hip.transfer(dev.index, t.data_ptr(), a.ctypes.data, a.nbytes, to_host=False)
+        return cls(t)
 
     # --- array protocol used by Signal ---------------------------------------------------
     @property
@@ -162,7 +169,13 @@ class DeviceArray:
 
     def get(self):
         """Host copy as numpy."""
-        return self._t.cpu().numpy()
+        t = self._t if self._t.is_contiguous() else self._t.contiguous()
+        if t.numel() == 0:
+            return t.cpu().numpy()
+        from . import _hip
+        out = np.empty(tuple(t.shape), dtype=self.dtype)
+        _hip.transfer(t.device.index, out.ctypes.data, t.data_ptr(), out.nbytes, to_host=True)
+        return out
 
     def __array__(self, dtype=None, copy=None):
         a = self.get()
