@@ -321,11 +321,11 @@ static int tr_rows(int S) {
 static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
     const int TN = tr_rows(S);
 #ifndef PBH_F64
-    if ((S & (S - 1)) == 0 && S <= 32 && N % TN == 0) {
+    if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
 #define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, N); break;
-            X(1) X(2) X(4) X(8) X(16) X(32)
+            X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
         }
         HIPCHECK(hipGetLastError());
@@ -344,12 +344,12 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     const int TN = tr_rows(S);
     int64_t done = 0;
 #ifndef PBH_F64
-    if ((S & (S - 1)) == 0 && S <= 32) {
+    if ((S & (S - 1)) == 0 && S <= 128) {
         const int64_t full = (stop - start) / TN;
         if (full > 0) {
             switch (S) {
 #define X(s) case s: hipLaunchKernelGGL(k_reinterleave_p2<s>, dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane); break;
-                X(1) X(2) X(4) X(8) X(16) X(32)
+                X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
             }
             HIPCHECK(hipGetLastError());

@@ -556,3 +556,16 @@ def test_series_major_arrays_in_other_ops():
     part = zs[100:2148]
     assert part.data.series_major_pitch() == zs.data.series_major_pitch()
     assert np.array_equal(np.asarray(part.data), x[100:2148])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nchan,npol", [(32, 2), (64, 2), (128, 1), (48, 2)])
+def test_many_series(nchan, npol):
+    """Wide blocks (S = 64, 128: the fast transposes; S = 96: the generic ones)."""
+    rng = np.random.default_rng(15)
+    shape = (1 << 15, nchan, npol) if npol > 1 else (1 << 15, nchan)
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(np.complex64)
+    z = make_signal(x, 1e6, 1e9)
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(3.0))
+    yr, _, _ = orc.coherent_dedispersion(x, 3.0, 1e6, 1e9)
+    assert y.shape == yr.shape and series_errors(y, yr)[0] < RTOL_L2
