@@ -178,13 +178,14 @@ struct ColpParams {
 };
 
 // ---- persistent column pass with deferred, interleaved stores --------------------------------------
-// As k_colp, but the outputs of tile i are not stored when they are ready: a burst of 32 stores per
-// thread blocks the wave until the write path has taken 128 KiB (writes are the slow direction: the
-// burst alone is ~45 % of an iteration).  Instead they stay in registers and are stored during tile
-// i+1's butterflies, two at a time at fft_tile's tick points, each followed by the load of the same
-// slot of tile i+2 -- the slot's registers pass from "output waiting to be stored" to "input on its
-// way", so the budget is two tiles of registers (the one being transformed, and the out/in slots).  Out-of-range descriptors (0 bytes) turn the first
-// iteration's stores and the last iterations' loads into no-ops without branches.
+// The outputs of tile i are not stored when they are ready: a burst of 32 stores per thread blocks
+// the wave until the write path has taken 128 KiB (writes are the slow direction: the burst alone
+// was ~45 % of an iteration).  They stay in registers and are stored during tile i+1's butterflies,
+// two at a time at fft_tile's tick points, each followed by the load of the same slot of tile i+2 --
+// the slot's registers pass from "output waiting to be stored" to "input on its way", so the budget
+// is two tiles of registers (the one being transformed, and the out/in slots).  Out-of-range
+// descriptors (0 bytes) turn the first iteration's stores and the last iterations' loads into
+// no-ops without branches.
 template <int M, int OP, int R>
 __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     constexpr int F = kTilePoints / M;
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     if (t >= ntile) return;
     uint32_t tn = t + G;
     int g = group_of(t);
-    rsrc_t rd = tile_rsrc(t);            // tile in v
-    rsrc_t rdo = make_rsrc(p.data, 0);   // tile whose outputs wait in `out` (none yet)
+    const rsrc_t rd0 = tile_rsrc(t);     // first tile, loaded up front
+    rsrc_t rdo = make_rsrc(p.data, 0);   // where the outputs waiting in `out` go (none yet)
     uint32_t tto = 0;                    // time index of that tile's first sample in this thread (N < 2^31)
     const uint32_t rowstep = (uint32_t)MR * (uint32_t)p.N2;
     double2 zbh, zbl, zsh, zsl;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     cf v[R], out[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        v[i] = buf_load(rd, voff, i * stepb);
+        v[i] = buf_load(rd0, voff, i * stepb);
         out[i] = make_cf(0, 0);
     }
 
@@ -323,7 +324,6 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         t = tn;
         tn = tnn;
         g = gn;
-        rd = rd2;
     }
     // drain: the last tile's outputs
 #pragma unroll
