@@ -385,6 +385,33 @@ __global__ __launch_bounds__(256) void k_bs_post_fft(const cf* __restrict__ conv
     }
 }
 
+// ---- circular filter of a non-power-of-two dedispersion plan (pbhip.hip: rebuild_circular_filter) ------
+// natural (N, nchan) <- plan-resident natural chirp [chan][k] (no rescaling)
+__global__ __launch_bounds__(256) void k_cf_nat(const cf* __restrict__ chirp, cf* __restrict__ nat, int64_t N, int nchan) {
+    const int64_t total = N * nchan;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / nchan;
+        const int c = (int)(e - k * nchan);
+        nat[e] = chirp[(int64_t)c * N + k];
+    }
+}
+// ext[chan][j] = scale * h[(j - (N-1)) mod N, chan] for j < 2N-1, else 0: the N-periodic impulse response laid
+// out so that a linear convolution with a block of N samples gives the circular one at outputs N-1 .. 2N-2
+__global__ __launch_bounds__(256) void k_cf_extend(const cf* __restrict__ h, cf* __restrict__ ext, int64_t N, int64_t L,
+                                                   int nchan, real scale) {
+    const int64_t total = L * nchan;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / L);
+        const int64_t j = e - (int64_t)c * L;
+        cf v = make_cf(0, 0);
+        if (j < 2 * N - 1) {
+            const cf t = h[((j + 1) % N) * nchan + c];
+            v = make_cf(t.x * scale, t.y * scale);
+        }
+        ext[e] = v;
+    }
+}
+
 // stft / istft through the Bluestein ring (nperseg not a power of two, or beyond one tile).  The ring
 // batch is B = nseg*S: column beta = g*S + s.  Time side: element (g, t, s) at g*N*S + t*S + s.
 // Channelised side: (g, c, k, e) at g*N*S + (c*N + (k + N/2) % N)*E + e, s = c*E + e.

@@ -107,6 +107,12 @@ struct pbh_plan {
     cf* bs_b = nullptr;         // b[n] = exp(-i pi n^2/N)
     cf* bs_a = nullptr;         // (bsL, S) pipeline input
     cf* bs_conv = nullptr;      // (bsL, S) pipeline output
+    // Dedispersion of such lengths is ONE power-of-two run: ifft_N(fft_N(x) H) is the circular convolution
+    // of x with h = ifft_N(H), i.e. outputs N-1 .. 2N-2 of the linear convolution of x with the N-periodic
+    // h laid out over 2N-1 taps, and that is the pipeline of a (bsL, nchan, npol) plan whose "chirp" is
+    // FFT_L of those taps and whose crop is [N-1+start, N-1+stop)  (rebuild_circular_filter)
+    pbh_plan* cfilt = nullptr;
+    cf* cf_in = nullptr;        // (bsL, S) zero-padded copy of the input
     void* stage_in = nullptr;   // device staging for host inputs
     void* stage_out = nullptr;  // device staging for host outputs
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
@@ -385,6 +391,17 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                                      IoLayout io = IoLayout()) {
     std::vector<Step> steps;
     const int S = p->S;
+    if (p->bsL && p->cfilt) {
+        const int64_t N = p->N, L = p->bsL;
+        cf* pad = p->cf_in;
+        steps.push_back({"k_pad", [=](hipStream_t st) {
+            HIPCHECK(hipMemcpyAsync(pad, in, sizeof(cf) * (size_t)N * S, hipMemcpyDeviceToDevice, st));
+            HIPCHECK(hipMemsetAsync(pad + N * S, 0, sizeof(cf) * (size_t)(L - N) * S, st));
+            return (int)PBH_OK;
+        }});
+        for (auto& s2 : build_steps(p->cfilt, pad, out)) steps.push_back(s2);
+        return steps;
+    }
     if (p->bsL) {
         const int64_t N = p->N, L = p->bsL, start = p->start, stop = p->stop;
         const int npol = p->npol;
@@ -702,6 +719,75 @@ const char* pbh_version(void) { return "pbhip 0.1.0 (gfx950)"; }
 static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
                        int64_t crop_start, int64_t crop_stop, bool plain_fft);
 
+// Non-power-of-two dedispersion plans: the (bsL, nchan, npol) convolution plan and its padded input.
+static int fft_c2c_ring(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse);
+
+static int setup_circular(pbh_plan* p) {
+    const int64_t N = p->N, L = p->bsL;
+#ifdef PBH_F64
+    const int dt = PBH_C128;
+#else
+    const int dt = PBH_C64;
+#endif
+    PBHCHECK(create_plan(&p->cfilt, p->device, L, p->nchan, p->npol, dt, (N - 1) + p->start, (N - 1) + p->stop, false));
+    p->cfilt->perm_w = 0;
+    p->owned_bytes += p->cfilt->owned_bytes;
+    PBHCHECK(dev_alloc(p, (void**)&p->cf_in, sizeof(cf) * (size_t)L * p->S));
+    return PBH_OK;
+}
+
+// (Re)build the convolution plan's filter spectrum from the plan-resident natural-order chirp H/N:
+// h/N = ifft_N(H/N) (Bluestein ring), taps = (N/L) * (h/N) extended N-periodically over 2N-1 samples,
+// G = FFT_L(taps) in plan order (the pipeline multiplies by G and its inverse transform is unnormalised).
+static int rebuild_circular_filter(pbh_plan* p) {
+    pbh_plan* q = p->cfilt;
+    if (!q) return PBH_OK;
+    const int64_t N = p->N, L = p->bsL;
+    const int nchan = p->nchan;
+    hipStream_t st = p->stream;
+    cf *nat = nullptr, *hh = nullptr;
+    PBHCHECK(dev_alloc(nullptr, (void**)&nat, sizeof(cf) * (size_t)N * nchan));
+    int rc = dev_alloc(nullptr, (void**)&hh, sizeof(cf) * (size_t)N * nchan);
+    auto grid = [](int64_t m) { int64_t g = (m + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
+    if (rc == PBH_OK) {
+        hipLaunchKernelGGL(k_cf_nat, dim3(grid(N * nchan)), dim3(256), 0, st, (const cf*)p->chirp, nat, N, nchan);
+        if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "k_cf_nat launch failed");
+    }
+    if (rc == PBH_OK) rc = fft_c2c_ring(p->device, st, nat, hh, N, nchan, 1);
+    if (rc == PBH_OK) {
+        hipLaunchKernelGGL(k_cf_extend, dim3(grid(L * nchan)), dim3(256), 0, st, (const cf*)hh, q->chirp, N, L, nchan,
+                           (real)((double)N / (double)L));
+        if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "k_cf_extend launch failed");
+    }
+    if (rc == PBH_OK) {
+        if (q->N1 == 1) {
+            // single tile: forward FFT of each channel's taps, out of place through `nat` (N*nchan >= ... may be
+            // smaller than L): use the padded-input buffer as scratch
+            for (int c = 0; c < nchan && rc == PBH_OK; ++c) {
+                if (hipMemcpyAsync(p->cf_in, q->chirp + (int64_t)c * L, sizeof(cf) * (size_t)L, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    rc = fail(PBH_ERR_HIP, "hipMemcpyAsync failed");
+                SmallParams sp{p->cf_in, q->chirp + (int64_t)c * L, nullptr, q->tw16k, 1, 1, 0, L, -1, (real)1};
+                if (rc == PBH_OK) rc = launch_small((int)L, sp, st);
+            }
+        } else {
+            BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
+            ColSide planar{LAYOUT_PLANAR, L, q->N2};
+            ColParams c1{q->chirp, q->chirp, planar, planar, LAYOUT_PLANAR, 0, 0, nchan, q->N2, (int64_t)nchan * q->N2, 0,
+                         tw, q->tw16k, 0, L, 0};
+            rc = launch_col<OP_FWD_TW>(q->N1, c1, st);
+            if (rc == PBH_OK) rc = launch_rowfft(q->N2, q->chirp, q->tw16k, (int64_t)nchan * q->N1, st);
+        }
+    }
+    hipStreamSynchronize(st);
+    hipFree(nat);
+    if (hh) hipFree(hh);
+    if (rc == PBH_OK) {
+        q->has_chirp = true;
+        q->has_phase = false;
+    }
+    return rc;
+}
+
 int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
                     int64_t crop_start, int64_t crop_stop) {
     return create_plan(out, device, nsample, nchan, npol, dtype, crop_start, crop_stop, false);
@@ -803,7 +889,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         if ((rc = dev_alloc(p, (void**)&p->work, sizeof(cf) * (size_t)p->S * nsample)) != PBH_OK) return bail(rc);
     }
     if (p->bsL) {
-        if ((rc = setup_bluestein(p)) != PBH_OK) return bail(rc);
+        if ((rc = plain_fft ? setup_bluestein(p) : setup_circular(p)) != PBH_OK) return bail(rc);
     }
     *out = p;
     return PBH_OK;
@@ -813,6 +899,8 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (!p) return PBH_OK;
     hipSetDevice(p->device);
     if (p->sub) pbh_plan_destroy(p->sub);
+    if (p->cfilt) pbh_plan_destroy(p->cfilt);
+    if (p->cf_in) hipFree(p->cf_in);
     void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv};
     for (void* q : ptrs)
@@ -851,7 +939,11 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->n2 = p->N2;
     info->variant = resolved_variant(p);
     info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3);
-    if (p->bsL) {
+    if (p->bsL && p->cfilt) {
+        pbh_plan_info_t sub;
+        pbh_plan_info(p->cfilt, &sub);
+        info->nkernel = 1 + sub.nkernel;
+    } else if (p->bsL) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->sub, &sub);
         info->nkernel = 3 + 2 * sub.nkernel;
@@ -886,6 +978,7 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));  // chan_freq_hz is a borrowed host buffer
     p->has_chirp = true;
+    PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
 }
 
@@ -905,6 +998,7 @@ int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
     p->has_phase = false;  // a user-supplied chirp is applied as the complex64 values it is
+    PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
 }
 
@@ -940,6 +1034,7 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
     p->has_phase = false;
+    PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
 }
 
