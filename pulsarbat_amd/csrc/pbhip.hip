@@ -219,7 +219,6 @@ static int launch_colq(int M, ColpParams prm, hipStream_t st) {
     int64_t tiles = (int64_t)prm.S * (prm.N2 / F);
     if (tiles > row_grid()) tiles = row_grid();
     if (colp_mode() < 2) prm.counter = nullptr;
-    if (prm.counter) HIPCHECK(hipMemsetAsync(prm.counter, 0, sizeof(unsigned), st));
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_colq<m, OP, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, ((kTilePoints / m) < 16 ? lds_tile_bytes<true>() : lds_tile_bytes<false>()) + 16);
         FOR_ALL_M(X)
@@ -282,7 +281,6 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
 #endif
     RowParams q = prm;
     if (spread == 2) q.counter = nullptr;
-    if (q.counter) HIPCHECK(hipMemsetAsync(q.counter, 0, sizeof(unsigned), st));
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 2>, q, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)
@@ -300,7 +298,6 @@ static bool row_phase_enabled() {
 static int launch_rowp(RowpParams prm, hipStream_t st) {
     int64_t tiles = (int64_t)prm.nchan * prm.N1;
     if (tiles > row_grid()) tiles = row_grid();
-    if (prm.counter) HIPCHECK(hipMemsetAsync(prm.counter, 0, sizeof(unsigned), st));
     return launch_tile_kernel(k_rowp<kTilePoints, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
 }
 #endif
@@ -516,6 +513,16 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         ColParams c3{work, out, planar, inter, el, sb, lo, S, N2, ncols, 0, tw, p->tw16k,
                      p->start, p->stop, p->start * S};
         steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_col<OP_TW_INV>(N1, c3, st); }});
+    }
+    // the persistent kernels' tile counters (three words behind the twiddle table) are zeroed once per
+    // run, ahead of the first kernel, instead of once per kernel
+    if (!steps.empty()) {
+        unsigned* ctr0 = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+        auto first = steps[0].launch;
+        steps[0].launch = [=](hipStream_t st) {
+            HIPCHECK(hipMemsetAsync(ctr0, 0, 3 * sizeof(unsigned), st));
+            return first(st);
+        };
     }
     return steps;
 }
