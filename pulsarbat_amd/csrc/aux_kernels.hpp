@@ -22,7 +22,16 @@ struct ChirpParams {
     real scale;
     int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
     float* phase = nullptr;  // optional second output, same order: the chirp's phase in revolutions, [-0.5, 0.5]
+    int P = 1;               // column transform split P x (N1/P): row r of a series holds k1 = r/Q + P*(r%Q)
 };
+
+// Row order of the planar work buffer when the column transform of length N1 is split into a radix-P stage
+// (k_radix_p) and P blocks of Q = N1/P rows (k_colq): block c, row d within it, holds k1 = c + P*d.
+__device__ __forceinline__ int64_t row_k1(int64_t r, int P, int N1) {
+    if (P <= 1) return r;
+    const int Q = N1 / P;
+    return r / Q + (int64_t)P * (r % Q);
+}
 
 __device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w) {
     if (perm_w == 0) return e2;
@@ -36,8 +45,8 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / p.N);
         const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t k1 = e / p.N2, k2 = row_bin(e - k1 * p.N2, p.N2, p.perm_w);
-        const int64_t k = k1 + (int64_t)p.N1 * k2;
+        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w);
+        const int64_t k = row_k1(r, p.P, p.N1) + (int64_t)p.N1 * k2;
         const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
         const double f = p.chan_freq[chan] + (double)bin * p.inv_ndt;
         const double dd = p.inv_ref - 1.0 / f;
@@ -56,14 +65,14 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
 __global__ __launch_bounds__(256) void k_chirp_reorder(const float2* __restrict__ nat_in, float2* __restrict__ nat_out,
                                                        const cf* __restrict__ plan_in, cf* __restrict__ plan_out,
                                                        int64_t N, int N1, int N2, int nchan, real scale,
-                                                       int to_plan, int perm_w) {
+                                                       int to_plan, int perm_w, int P) {
     const int64_t total = N * nchan;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / N);
         const int64_t e = d - (int64_t)chan * N;
-        const int64_t k1 = e / N2, k2 = row_bin(e - k1 * N2, N2, perm_w);
-        const int64_t k = k1 + (int64_t)N1 * k2;
+        const int64_t r = e / N2, k2 = row_bin(e - r * N2, N2, perm_w);
+        const int64_t k = row_k1(r, P, N1) + (int64_t)N1 * k2;
         const int64_t nat = k * nchan + chan;
         if (to_plan) {
             const float2 v = nat_in[nat];
@@ -385,6 +394,50 @@ __global__ __launch_bounds__(256) void k_bs_post_fft(const cf* __restrict__ conv
     }
 }
 
+// ---- radix-P stage of a long column transform (N1 = P * Q, Q rows per column tile) --------------------------
+// When N1 exceeds 2^14/16 a column tile would be fewer than 16 columns wide (partial 128-B lines).  The
+// transform over n1 = Q*a + b is then split: this elementwise pass does the P-point DFT over a for every
+// (series, b, n2) -- P samples N/P apart, fully coalesced -- and the twiddle W_N1^{b c}; k_colq then runs
+// Q-point transforms on the P row blocks (block c, row d holds k1 = c + P*d).  The inverse mirrors it:
+// conj twiddle, inverse P-point DFT, after the blocks' inverse transforms.  In place.
+template <int P, int DIR>
+__global__ __launch_bounds__(256) void k_radix_p(cf* __restrict__ data, int64_t plane, int S, int64_t chunk, int N2, int N1) {
+    const int64_t total = (int64_t)S * chunk;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = e / chunk, np = e - s * chunk;
+        cf* base = data + s * plane + np;
+        cf v[P];
+#pragma unroll
+        for (int a = 0; a < P; ++a) v[a] = base[(int64_t)a * chunk];
+        // W_N1^{b c}, c = 1..P-1, from one float64 sincospi and a float64 product chain
+        const int64_t b = np / N2;
+        double sn, cs;
+        sincospi(2.0 * (double)b / (double)N1, &sn, &cs);
+        const double2 w1 = make_double2(cs, DIR < 0 ? -sn : sn);
+        if (DIR < 0) Dft<P, -1>::run(v);
+        double2 w = w1;
+#pragma unroll
+        for (int c = 1; c < P; ++c) {
+            v[c] = cmul(v[c], make_cf((real)w.x, (real)w.y));
+            w = make_double2(w.x * w1.x - w.y * w1.y, w.x * w1.y + w.y * w1.x);
+        }
+        if (DIR > 0) Dft<P, +1>::run(v);
+#pragma unroll
+        for (int a = 0; a < P; ++a) base[(int64_t)a * chunk] = v[a];
+    }
+}
+
+// rows of nplanes planar (N1 x N2) arrays from natural k1 order into the split order: out[r] = in[row_k1(r)]
+__global__ __launch_bounds__(256) void k_row_permute(const cf* __restrict__ in, cf* __restrict__ out, int N1, int N2,
+                                                     int P, int nplanes) {
+    const int64_t total = (int64_t)nplanes * N1 * N2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / N2, j = e - row * N2;
+        const int64_t pl = row / N1, r = row - pl * N1;
+        out[e] = in[(pl * N1 + row_k1(r, P, N1)) * N2 + j];
+    }
+}
+
 // ---- circular filter of a non-power-of-two dedispersion plan (pbhip.hip: rebuild_circular_filter) ------
 // natural (N, nchan) <- plan-resident natural chirp [chan][k] (no rescaling)
 __global__ __launch_bounds__(256) void k_cf_nat(const cf* __restrict__ chirp, cf* __restrict__ nat, int64_t N, int nchan) {
@@ -466,8 +519,8 @@ __global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const doub
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / p.N);
         const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t k1 = e / p.N2, k2 = row_bin(e - k1 * p.N2, p.N2, p.perm_w);
-        const int64_t k = k1 + (int64_t)p.N1 * k2;
+        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w);
+        const int64_t k = row_k1(r, p.P, p.N1) + (int64_t)p.N1 * k2;
         const double a = arg[chan];
         if (mode == 0) {
             const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;

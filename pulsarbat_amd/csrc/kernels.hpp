@@ -175,6 +175,7 @@ struct ColpParams {
     const cf* ld = nullptr;
     int64_t ld_plane = 0;
     int64_t st_shift = 0;
+    int P = 1;  // column transform split P x M (k_radix_p did the radix-P stage): a series is P blocks of M rows
 };
 
 // ---- persistent column pass with deferred, interleaved stores --------------------------------------
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     const int tid = threadIdx.x;
     const int f = tid % F, tau = tid / F;
     const uint32_t ngrp = (uint32_t)(p.N2 / F);
-    const uint32_t ntile = ngrp * (uint32_t)p.S;
+    const uint32_t ntile = ngrp * (uint32_t)p.S * (uint32_t)p.P;   // (series, row block, column group)
     const int voff = (tau * p.N2 + f) * (int)sizeof(cf);
     const int stepb = MR * p.N2 * (int)sizeof(cf);
     const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * p.N2 + F) * (int64_t)sizeof(cf));
@@ -208,20 +209,26 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
-    auto group_of = [&](uint32_t t) -> int { return p.order ? (int)(t / (uint32_t)p.S) : (int)(t % ngrp); };
-    auto series_of = [&](uint32_t t) -> int { return p.order ? (int)(t % (uint32_t)p.S) : (int)(t / ngrp); };
+    // tile t = (series s, row block c, column group g), g fastest
+    auto group_of = [&](uint32_t t) -> int { return (int)(t % ngrp); };
+    auto block_of = [&](uint32_t t) -> int { return (int)((t / ngrp) % (uint32_t)p.P); };
+    auto series_of = [&](uint32_t t) -> int { return (int)(t / (ngrp * (uint32_t)p.P)); };
+    const int64_t blk = (int64_t)M * p.N2;   // elements per row block
     const cf* ldb = p.ld ? p.ld : p.data;
     const int64_t ldp = p.ld ? p.ld_plane : p.plane;
     auto tile_rsrc = [&](uint32_t t) {   // where tile t is loaded from
-        return t < ntile ? make_rsrc(ldb + (int64_t)series_of(t) * ldp + (int64_t)group_of(t) * F, tile_bytes)
+        return t < ntile ? make_rsrc(ldb + (int64_t)series_of(t) * ldp + block_of(t) * blk + (int64_t)group_of(t) * F, tile_bytes)
                          : make_rsrc(p.data, 0);
     };
     auto store_rsrc = [&](uint32_t t) {  // where its outputs go (the base may lie before the array when the
                                          // first columns are cropped: only in-range offsets are ever used)
-        return make_rsrc(p.data + (int64_t)series_of(t) * p.plane + (int64_t)group_of(t) * F - p.st_shift, tile_bytes);
+        return make_rsrc(p.data + (int64_t)series_of(t) * p.plane + block_of(t) * blk + (int64_t)group_of(t) * F - p.st_shift,
+                         tile_bytes);
     };
-    auto load_tables = [&](int n2, double2& bh, double2& bl, double2& sh, double2& sl) {
-        const int64_t pb = ((int64_t)n2 * tau) & p.tw.mask, ps = ((int64_t)n2 * MR) & p.tw.mask;
+    // inter-pass twiddle W_N^{n2 k1}, k1 = c + P*(tau + i*MR): base and step of the float64 recurrence
+    auto load_tables = [&](int n2, int c, double2& bh, double2& bl, double2& sh, double2& sl) {
+        const int64_t pb = ((int64_t)n2 * (c + (int64_t)p.P * tau)) & p.tw.mask;
+        const int64_t ps = ((int64_t)n2 * p.P * MR) & p.tw.mask;
         bh = p.tw.hi[pb >> shift];
         bl = p.tw.lo[pb & lomask];
         sh = p.tw.hi[ps >> shift];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     uint32_t tto = 0;                    // time index of that tile's first sample in this thread (N < 2^31)
     const uint32_t rowstep = (uint32_t)MR * (uint32_t)p.N2;
     double2 zbh, zbl, zsh, zsl;
-    load_tables(g * F + f, zbh, zbl, zsh, zsl);
+    load_tables(g * F + f, block_of(t), zbh, zbl, zsh, zsl);
     cf v[R], out[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         const uint32_t tnn = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);  // wave-uniform: descriptors stay in SGPRs
         // tables of the next tile: after every request above, before nothing that has to wait for them
         const int gn = more ? group_of(tn) : g;
-        if (more) load_tables(gn * F + f, zbh, zbl, zsh, zsl);
+        if (more) load_tables(gn * F + f, block_of(tn), zbh, zbl, zsh, zsl);
         if constexpr (OP == OP_TW_INV) {
 #pragma unroll
             for (int i = 0; i < R; ++i) out[i] = v[i];

@@ -86,6 +86,7 @@ struct pbh_plan {
     int64_t N = 0, start = 0, stop = 0;
     int nchan = 0, npol = 0, S = 0;
     int N1 = 1, N2 = 1;
+    int P = 1;  // N1 = P * Q: column transform split into a radix-P stage (k_radix_p) and P blocks of Q rows (k_colq)
     int variant = PBH_VARIANT_AUTO;
     hipStream_t stream = nullptr;
     bool has_chirp = false;
@@ -131,6 +132,7 @@ static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
 
 static int resolved_variant(const pbh_plan* p) {
     if (p->N1 == 1) return PBH_VARIANT_DIRECT3;  // single tile: no passes to choose
+    if (p->P > 1) return PBH_VARIANT_PLANAR5;    // long blocks: only the planar pipeline has the split column pass
     if (p->variant != PBH_VARIANT_AUTO) return p->variant;
     // direct3 touches full 128-B lines only when a 16-column tile spans whole time samples of few
     // series; with many interleaved series its planar side degenerates to 8-byte pieces
@@ -216,7 +218,7 @@ static int launch_colq(int M, ColpParams prm, hipStream_t st) {
     const int F = kTilePoints / M;
     if (prm.N2 % F != 0) return fail(PBH_ERR_STATE, "k_colq needs whole column groups");
     prm.order = 0;
-    int64_t tiles = (int64_t)prm.S * (prm.N2 / F);
+    int64_t tiles = (int64_t)prm.S * prm.P * (prm.N2 / F);
     if (tiles > row_grid()) tiles = row_grid();
     if (colp_mode() < 2) prm.counter = nullptr;
     switch (M) {
@@ -225,6 +227,21 @@ static int launch_colq(int M, ColpParams prm, hipStream_t st) {
 #undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "column pass length " + std::to_string(M));
+}
+
+template <int DIR>
+static int launch_radix(int P, cf* data, int64_t plane, int S, int64_t N, int N2, int N1, hipStream_t st) {
+    const int64_t chunk = N / P;
+    int64_t blocks = ((int64_t)S * chunk + 255) / 256;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    switch (P) {
+#define X(pp) case pp: hipLaunchKernelGGL((k_radix_p<pp, DIR>), dim3((unsigned)blocks), dim3(256), 0, st, data, plane, S, chunk, N2, N1); break;
+        X(2) X(4) X(8) X(16)
+#undef X
+        default: return fail(PBH_ERR_UNSUPPORTED, "radix-P stage: P must be 2, 4, 8 or 16");
+    }
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
 }
 
 static int launch_row(int M, const RowParams& prm, hipStream_t st) {
@@ -448,15 +465,21 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 return launch_deinterleave(in, work, N, S, st);
             }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
-        const bool colp = (colp_mode() != 0 || in_sm || out_sm) && N2 % (kTilePoints / N1) == 0 && N < (1LL << 31);
+        const int P = p->P, Q = N1 / P;
+        const bool colp = P > 1 || ((colp_mode() != 0 || in_sm || out_sm) && Q <= kTilePoints &&
+                                    N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
         if (in_sm) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
             cp1.ld = in;
             cp1.ld_plane = io.in_pitch;
         }
+        if (P > 1) {
+            cp1.P = P;
+            steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_radix<-1>(P, work, N, S, N, N2, N1, st); }});
+        }
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
-            return colp ? launch_colq<OP_FWD_TW>(N1, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
+            return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
         }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
                      reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
@@ -477,9 +500,16 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             cp3.plane = io.out_pitch;
             cp3.st_shift = start;
         }
+        if (P > 1) {   // the time order only exists after the inverse radix-P stage: no crop in the column pass
+            cp3.P = P;
+            cp3.crop_start = 0;
+            cp3.crop_stop = N;
+        }
         steps.push_back({"k_col_inv", [=](hipStream_t st) {
-            return colp ? launch_colq<OP_TW_INV>(N1, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
+            return colp ? launch_colq<OP_TW_INV>(Q, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
+        if (P > 1)
+            steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_radix<+1>(P, work, N, S, N, N2, N1, st); }});
         if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
@@ -701,6 +731,11 @@ static int setup_bluestein(pbh_plan* p) {
                      q->tw16k, 0, L, 0};
         PBHCHECK(launch_col<OP_FWD_TW>(q->N1, c1, st));
         PBHCHECK(launch_rowfft(q->N2, q->chirp, q->tw16k, q->N1, st));
+        if (q->P > 1) {   // the sub-plan walks its rows in the split order (row_k1)
+            hipLaunchKernelGGL(k_row_permute, dim3(4096), dim3(256), 0, st, (const cf*)q->chirp, p->bs_a, q->N1, q->N2, q->P, 1);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipMemcpyAsync(q->chirp, p->bs_a, sizeof(cf) * (size_t)L, hipMemcpyDeviceToDevice, st));
+        }
     }
     HIPCHECK(hipStreamSynchronize(st));
     q->has_chirp = true;
@@ -783,6 +818,13 @@ static int rebuild_circular_filter(pbh_plan* p) {
                          tw, q->tw16k, 0, L, 0};
             rc = launch_col<OP_FWD_TW>(q->N1, c1, st);
             if (rc == PBH_OK) rc = launch_rowfft(q->N2, q->chirp, q->tw16k, (int64_t)nchan * q->N1, st);
+            if (rc == PBH_OK && q->P > 1) {   // the convolution plan walks its rows in the split order (row_k1)
+                hipLaunchKernelGGL(k_row_permute, dim3(4096), dim3(256), 0, st, (const cf*)q->chirp, p->cf_in, q->N1, q->N2,
+                                   q->P, nchan);
+                if (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(q->chirp, p->cf_in, sizeof(cf) * (size_t)L * nchan, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    rc = fail(PBH_ERR_HIP, "row permutation of the filter spectrum failed");
+            }
         }
     }
     hipStreamSynchronize(st);
@@ -845,6 +887,21 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         const int l2 = (n - PBH_LOG2R < kTileLog2) ? n - PBH_LOG2R : kTileLog2;
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
+    }
+    if (p->N1 > 1) {
+        // column tiles whose rows are narrower than a 128-byte line are avoided by splitting N1 = P * Q with
+        // Q rows per tile such that a tile row is one line; PBH_QMAX overrides Q (tests exercise the split at
+        // small sizes)
+        int qmax = kTilePoints * (int)sizeof(cf) / 128;
+        if (const char* e = getenv("PBH_QMAX")) {
+            const int v = atoi(e);
+            if (v >= PBH_R && (v & (v - 1)) == 0 && v <= kTilePoints) qmax = v;
+        }
+        // worth it from 32-byte pieces down (N1 >= 4 qmax): at N1 = 2 qmax the two extra passes cost more than
+        // the 64-byte pieces do (complex64 2^25 x 16 series: 11.3 ms split vs 9.5 ms unsplit; complex128 2^24: 12.2 vs 9.8)
+        const int pmin = getenv("PBH_QMAX") ? 2 : 4;
+        if (p->N1 >= pmin * qmax && p->N1 / qmax <= 16 && nsample < (1LL << 31) && p->N2 % (kTilePoints / qmax) == 0)
+            p->P = p->N1 / qmax;
     }
     {
         const char* e = getenv("PBH_ROW2");
@@ -945,7 +1002,7 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->n1 = p->N1;
     info->n2 = p->N2;
     info->variant = resolved_variant(p);
-    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3);
+    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) + (p->P > 1 ? 2 : 0);
     if (p->bsL && p->cfilt) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->cfilt, &sub);
@@ -972,6 +1029,7 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     HIPCHECK(hipMemcpyAsync(p->chan_freq, chan_freq_hz, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, coeff_hz, 1.0 / ((double)p->N * dt_s), 1.0 / ref_freq_hz,
                    p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
+    cp.P = p->P;
     p->has_phase = false;
 #ifndef PBH_F64
     // the fused row pass of multi-pass float32 plans reads the chirp as a phase (k_rowp)
@@ -1000,7 +1058,7 @@ int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
         src = (const float2*)p->stage_in;
     }
     hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, (float2*)nullptr,
-                       (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w);
+                       (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
@@ -1020,7 +1078,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
         dst = (float2*)p->stage_out;
     }
     hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const float2*)nullptr, dst,
-                       (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w);
+                       (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w, p->P);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
         HIPCHECK(xfer_d2h(chirp_c64, dst, bytes, p->stream));
@@ -1036,6 +1094,7 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipSetDevice(p->device));
     HIPCHECK(hipMemcpyAsync(p->chan_freq, arg, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, 0.0, 0.0, 0.0, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
+    cp.P = p->P;
     hipLaunchKernelGGL(k_chirp_special, dim3(2048), dim3(256), 0, p->stream, cp, (const double*)p->chan_freq, mode);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));
@@ -1242,7 +1301,8 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     HIPCHECK(hipSetDevice(p->device));
     if (nout <= 0) return PBH_OK;
     const bool any_sm = in_layout == PBH_LAYOUT_SERIES_MAJOR || out_layout == PBH_LAYOUT_SERIES_MAJOR;
-    if (any_sm && (p->bsL || p->N1 == 1 || p->N2 % (kTilePoints / p->N1) != 0 || p->N >= (1LL << 31)))
+    if (any_sm && (p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+                   p->N >= (1LL << 31)))
         return fail(PBH_ERR_UNSUPPORTED, "series-major I/O needs a multi-pass power-of-two plan (nsample > one tile)");
     IoLayout io;
     io.in_layout = in_layout;
@@ -1371,7 +1431,8 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
     if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
     if (in_layout == PBH_LAYOUT_SERIES_MAJOR) {
         if (in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
-        if (p->bsL || p->N1 == 1 || p->N2 % (kTilePoints / p->N1) != 0 || p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
+        if (p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+            p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
             p->nchan > 65535)
             return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan and nscrunch % 64 == 0");
     } else {

@@ -569,3 +569,64 @@ def test_many_series(nchan, npol):
     y = pb.coherent_dedispersion(z.to_device(), pb.DM(3.0))
     yr, _, _ = orc.coherent_dedispersion(x, 3.0, 1e6, 1e9)
     assert y.shape == yr.shape and series_errors(y, yr)[0] < RTOL_L2
+
+
+# ---- long blocks: column transform split into a radix-P stage and P row blocks (k_radix_p + k_colq) ----------
+@pytest.fixture
+def small_qmax(monkeypatch):
+    """Force the split at small sizes: at most 32 (complex64) / 16 (complex128) rows per column tile."""
+    from pulsarbat_amd.transforms.dedispersion import clear_plan_cache
+    clear_plan_cache()
+    yield monkeypatch
+    monkeypatch.delenv("PBH_QMAX", raising=False)
+    clear_plan_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dm,dtype,qmax,nk", [
+    ((1 << 20, 2, 2), 20.0, np.complex64, 32, 7),    # N1 = 64  -> P = 2
+    ((1 << 21, 3, 2), 30.0, np.complex64, 32, 7),    # N1 = 128 -> P = 4
+    ((1 << 22, 1, 2), 30.0, np.complex64, 32, 7),    # N1 = 256 -> P = 8, S = 2 (would be direct3)
+    ((1 << 23, 1), 30.0, np.complex64, 32, 7),       # N1 = 512 -> P = 16, one series
+    ((1 << 19, 2, 2), 10.0, np.complex128, 16, 7),   # float64: N2 = 2^13, N1 = 64 -> P = 4
+    ((1 << 20, 4), 10.0, np.complex128, 32, 7),      # N1 = 128 -> P = 4
+])
+def test_split_column_transform(small_qmax, shape, dm, dtype, qmax, nk):
+    small_qmax.setenv("PBH_QMAX", str(qmax))
+    rng = np.random.default_rng(21)
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(dtype)
+    z = make_signal(x, 1e6, 1e9, start_time=pb.Time(56000.0, format="mjd"))
+    yr, start, stop = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    tol = RTOL_L2 if dtype == np.complex64 else RTOL_F64
+    from pulsarbat_amd.transforms.dedispersion import _prepare
+    plan, xin, _, _ = _prepare(z.to_device(), pb.DM(dm), None, None, "auto")
+    assert plan.info["nkernel"] == nk
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(dm))
+    assert y.shape == yr.shape and series_errors(y, yr)[0] < tol
+    # user chirp (uploaded in the reference's order), chirp download, and the fused detect tail use the same row order
+    chirp = orc.chirp_from_signal(dm, x.shape, 1e6, 1e9)
+    y2 = pb.coherent_dedispersion(z.to_device(), pb.DM(dm), chirp=chirp)
+    assert series_errors(y2, yr)[0] < tol
+    got = pb.DM(dm).chirp_from_signal(z.to_device())
+    assert np.abs(np.asarray(got).reshape(chirp.shape) - chirp).max() < 2.5e-7
+    if x.ndim == 3:
+        a, s0 = pb.dedisperse_detect(z.to_device(), pb.DM(dm), mode="I", nscrunch=64)
+        want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], 64)
+        assert s0 == start and np.abs(np.asarray(a) - want).max() < 3e-5 * np.abs(want).max()
+    # series-major arrays fall back to one contiguous copy for these plans
+    zs = type(z).like(z, z.to_device().data.to_series_major())
+    assert series_errors(pb.coherent_dedispersion(zs, pb.DM(dm)), yr)[0] < tol
+
+
+@pytest.mark.gpu
+def test_split_column_transform_nonpow2(small_qmax):
+    """A non-power-of-two length whose convolution plan (L = 2^21) uses the split: filter rows permuted."""
+    small_qmax.setenv("PBH_QMAX", "32")
+    rng = np.random.default_rng(22)
+    x = (rng.standard_normal((700001, 2, 2)) + 1j * rng.standard_normal((700001, 2, 2))).astype(np.complex64)
+    z = make_signal(x, 1e6, 1e9)
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(7.0))
+    yr, _, _ = orc.coherent_dedispersion(x, 7.0, 1e6, 1e9)
+    assert series_errors(y, yr)[0] < RTOL_L2
+    f = pb.fft.fft(z.to_device().data, axis=0)      # plain ring transform (its sub-plan is split too)
+    assert np.linalg.norm(np.asarray(f) - np.fft.fft(x, axis=0)) / np.linalg.norm(np.fft.fft(x, axis=0)) < 2e-6
