@@ -204,6 +204,146 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
     }
 }
 
+// ---- layout passes with the radix-P stage of a long column transform folded in ----------------------------
+// (see k_radix_p).  A workgroup handles the same TN time samples of all P chunks (N/P apart): forward it
+// reads P interleaved tiles, does the P-point DFT + twiddle across them in registers and writes P planar
+// tiles; inverse it reads P planar tiles, undoes the stage and writes P interleaved tiles, cropped.  Long
+// blocks are back to five passes.  E elements per chunk tile, chosen so a thread holds <= 32 float4.
+template <int P>
+struct RadixTile {
+    static constexpr int E = P <= 4 ? 4096 : 4096 * 4 / P;
+};
+template <int P>
+__device__ __forceinline__ void radix_twiddles(cf (&tw)[P], int64_t b, int N1, int dir) {
+    double sn, cs;
+    sincospi(2.0 * (double)b / (double)N1, &sn, &cs);
+    const double2 w1 = make_double2(cs, dir < 0 ? -sn : sn);
+    double2 w = w1;
+    tw[0] = make_cf(1, 0);
+#pragma unroll
+    for (int c = 1; c < P; ++c) {
+        tw[c] = make_cf((real)w.x, (real)w.y);
+        w = make_double2(w.x * w1.x - w.y * w1.y, w.x * w1.y + w.y * w1.x);
+    }
+}
+
+template <int S, int P>
+__global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, cf* __restrict__ out, int64_t chunk,
+                                                     int64_t plane, int N2, int N1) {
+    constexpr int E = RadixTile<P>::E, TN = E / S, LD = TN + 1, NV = E / 2 / 256;
+    __shared__ cf lds[S * LD];
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    float4 v[P][NV];
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const float4* src = reinterpret_cast<const float4*>(in + ((int64_t)a * chunk + n0) * S);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[a][j] = src[threadIdx.x + 256 * j];
+    }
+    cf tw[P];
+    radix_twiddles<P>(tw, n0 / N2, N1, -1);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cf x[P];
+#pragma unroll
+            for (int a = 0; a < P; ++a) x[a] = h ? make_cf(v[a][j].z, v[a][j].w) : make_cf(v[a][j].x, v[a][j].y);
+            Dft<P, -1>::run(x);
+#pragma unroll
+            for (int c = 1; c < P; ++c) x[c] = cmul(x[c], tw[c]);
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                if (h) { v[c][j].z = x[c].x; v[c][j].w = x[c].y; }
+                else { v[c][j].x = x[c].x; v[c][j].y = x[c].y; }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 2 * (threadIdx.x + 256 * j);
+            const int n = e / S, s = e % S;
+            lds[s * LD + n] = make_cf(v[c][j].x, v[c][j].y);
+            lds[(s + 1) * LD + n] = make_cf(v[c][j].z, v[c][j].w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int pidx = threadIdx.x + 256 * j;
+            const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
+            const cf x0 = lds[s * LD + n], x1 = lds[s * LD + n + 1];
+            *reinterpret_cast<float4*>(out + (int64_t)s * plane + (int64_t)c * chunk + n0 + n) = make_float4(x0.x, x0.y, x1.x, x1.y);
+        }
+        __syncthreads();
+    }
+}
+
+template <int S, int P>
+__global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, cf* __restrict__ out, int64_t chunk,
+                                                     int64_t plane, int N2, int N1, int64_t start, int64_t stop) {
+    constexpr int E = RadixTile<P>::E, TN = E / S, LD = TN + 1, NV = E / 2 / 256;
+    __shared__ cf lds[S * LD];
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    // nothing to do when none of the P tiles reaches the kept range
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < P; ++a) any |= ((int64_t)a * chunk + n0 < stop) && ((int64_t)a * chunk + n0 + TN > start);
+    if (!any) return;
+    float4 v[P][NV];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int pidx = threadIdx.x + 256 * j;
+            const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
+            const float4 t = *reinterpret_cast<const float4*>(in + (int64_t)s * plane + (int64_t)c * chunk + n0 + n);
+            lds[s * LD + n] = make_cf(t.x, t.y);
+            lds[s * LD + n + 1] = make_cf(t.z, t.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 2 * (threadIdx.x + 256 * j);
+            const int n = e / S, s = e % S;
+            const cf x0 = lds[s * LD + n], x1 = lds[(s + 1) * LD + n];
+            v[c][j] = make_float4(x0.x, x0.y, x1.x, x1.y);
+        }
+        __syncthreads();
+    }
+    cf tw[P];
+    radix_twiddles<P>(tw, n0 / N2, N1, +1);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cf x[P];
+#pragma unroll
+            for (int c = 0; c < P; ++c) x[c] = h ? make_cf(v[c][j].z, v[c][j].w) : make_cf(v[c][j].x, v[c][j].y);
+#pragma unroll
+            for (int c = 1; c < P; ++c) x[c] = cmul(x[c], tw[c]);
+            Dft<P, +1>::run(x);
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                if (h) { v[a][j].z = x[a].x; v[a][j].w = x[a].y; }
+                else { v[a][j].x = x[a].x; v[a][j].y = x[a].y; }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const int64_t t0 = (int64_t)a * chunk + n0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 2 * (threadIdx.x + 256 * j);
+            const int64_t t = t0 + e / S;
+            if (t >= start && t < stop)
+                *reinterpret_cast<float4*>(out + (t - start) * S + (e % S)) = v[a][j];
+        }
+    }
+}
+
 #endif  // !PBH_F64
 
 // ---- detection (pulsarbat/core.py:766-774, 930-966), optional time scrunch -----------------------------

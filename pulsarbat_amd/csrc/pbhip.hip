@@ -386,6 +386,66 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     return PBH_OK;
 }
 
+// Layout passes with the radix-P stage folded in (float32, 2 <= S <= 128 a power of two, tiles of >= 16 samples).
+static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
+#ifdef PBH_F64
+    (void)S; (void)P; (void)N; (void)N2;
+    return false;
+#else
+    static const bool on = [] { const char* e = getenv("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
+    if (!on || P < 2 || P > 16 || S < 2 || S > 128 || (S & (S - 1)) != 0) return false;
+    const int E = P <= 4 ? 4096 : 4096 * 4 / P, TN = E / S;
+    return TN >= 16 && (N / P) % TN == 0 && N2 % TN == 0;
+#endif
+}
+#ifndef PBH_F64
+template <int S>
+static int launch_deint_radix_s(int P, const cf* in, cf* work, int64_t N, int N2, int N1, hipStream_t st) {
+    const int64_t chunk = N / P;
+    switch (P) {
+#define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1); break;
+        X(2) X(4) X(8) X(16)
+#undef X
+    }
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+template <int S>
+static int launch_reint_radix_s(int P, const cf* work, cf* out, int64_t N, int N2, int N1, int64_t start, int64_t stop,
+                                hipStream_t st) {
+    const int64_t chunk = N / P;
+    switch (P) {
+#define X(pp) case pp: hipLaunchKernelGGL((k_reint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, work, out, chunk, N, N2, N1, start, stop); break;
+        X(2) X(4) X(8) X(16)
+#undef X
+    }
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+#endif
+static int launch_deint_radix(int S, int P, const cf* in, cf* work, int64_t N, int N2, int N1, hipStream_t st) {
+#ifndef PBH_F64
+    switch (S) {
+#define X(s) case s: return launch_deint_radix_s<s>(P, in, work, N, N2, N1, st);
+        X(2) X(4) X(8) X(16) X(32) X(64) X(128)
+#undef X
+    }
+#endif
+    return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
+}
+static int launch_reint_radix(int S, int P, const cf* work, cf* out, int64_t N, int N2, int N1, int64_t start,
+                              int64_t stop, hipStream_t st) {
+    if (stop <= start) return PBH_OK;
+#ifndef PBH_F64
+    switch (S) {
+#define X(s) case s: return launch_reint_radix_s<s>(P, work, out, N, N2, N1, start, stop, st);
+        X(2) X(4) X(8) X(16) X(32) X(64) X(128)
+#undef X
+    }
+#endif
+    return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
+}
+
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
 struct DetectTail {
     real* out = nullptr;   // non-null: replace the final layout pass by detect + scrunch into `out`
@@ -460,7 +520,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
     if (variant == PBH_VARIANT_PLANAR5 || in_sm || out_sm) {
         const int64_t N = p->N, start = p->start, stop = p->stop;
-        if (!in_sm)
+        const bool fuse_radix = p->P > 1 && !in_sm && !out_sm && radix_layout_ok(S, p->P, N, N2);
+        if (fuse_radix) {
+            const int Pf = p->P;
+            steps.push_back({"k_deinterleave", [=](hipStream_t st) {
+                return launch_deint_radix(S, Pf, in, work, N, N2, N1, st);
+            }});
+        } else if (!in_sm)
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
                 return launch_deinterleave(in, work, N, S, st);
             }});
@@ -476,7 +542,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         }
         if (P > 1) {
             cp1.P = P;
-            steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_radix<-1>(P, work, N, S, N, N2, N1, st); }});
+            if (!fuse_radix)
+                steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_radix<-1>(P, work, N, S, N, N2, N1, st); }});
         }
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
             return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
@@ -508,7 +575,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         steps.push_back({"k_col_inv", [=](hipStream_t st) {
             return colp ? launch_colq<OP_TW_INV>(Q, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
-        if (P > 1)
+        const bool fuse_out = fuse_radix && !tail.out;   // the detect tail reads time-ordered planar data
+        if (P > 1 && !fuse_out)
             steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_radix<+1>(P, work, N, S, N, N2, N1, st); }});
         if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
@@ -519,6 +587,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                                    (const cf*)work, tail.out, N, start, nout, nchan, npol, tail.mode, tail.nscrunch);
                 HIPCHECK(hipGetLastError());
                 return (int)PBH_OK;
+            }});
+        } else if (fuse_out) {
+            steps.push_back({"k_reinterleave", [=](hipStream_t st) {
+                return launch_reint_radix(S, P, work, out, N, N2, N1, start, stop, st);
             }});
         } else if (!out_sm) {
             steps.push_back({"k_reinterleave", [=](hipStream_t st) {
