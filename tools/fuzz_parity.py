@@ -12,9 +12,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 n_ok = n_bad = 0
 worst = {"c64": 0.0, "c128": 0.0}
+import os
+from pulsarbat_amd.transforms.dedispersion import clear_plan_cache
 while time.time() - t0 < budget:
+    # sometimes force the split column transform (long-block code path) at these small sizes
+    q = rng.choice([0, 0, 32, 64])
+    if q:
+        os.environ["PBH_QMAX"] = str(int(q))
+    else:
+        os.environ.pop("PBH_QMAX", None)
+    clear_plan_cache()
     pow2 = rng.random() < 0.75
-    n = 1 << int(rng.integers(12, 21)) if pow2 else int(rng.integers(2000, 400000))
+    n = 1 << int(rng.integers(12, 23)) if pow2 else int(rng.integers(2000, 400000))
     nchan = int(rng.integers(1, 10))
     npol = int(rng.choice([1, 2]))
     dtype = np.complex64 if rng.random() < 0.7 else np.complex128
@@ -50,7 +59,7 @@ while time.time() - t0 < budget:
     worst[key] = max(worst[key], err)
     if y.shape != yr.shape or not err < tol:
         n_bad += 1
-        print(f"BAD n={n} nchan={nchan} npol={npol} {key} sr={sr} fc={fc} dm={dm} {mode} {variant} err={err:.3e}", flush=True)
+        print(f"BAD n={n} nchan={nchan} npol={npol} {key} sr={sr} fc={fc} dm={dm} {mode} {variant} qmax={q} err={err:.3e}", flush=True)
     else:
         n_ok += 1
 print(f"cases ok {n_ok}, bad {n_bad}, worst rel err c64 {worst['c64']:.2e}, c128 {worst['c128']:.2e}, {time.time() - t0:.0f} s")
