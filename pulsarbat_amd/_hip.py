@@ -250,8 +250,8 @@ class Plan:
         """True when pbh_dedisperse_layout accepts series-major ends for this plan."""
         n = self.nsample
         info = self.info
-        # 3 or 5 kernels: the plain multi-pass pipelines; 7 = long blocks with the split column pass (no layout-aware entry yet)
-        return (n & (n - 1)) == 0 and info["n1"] > 1 and info["nkernel"] in (3, 5)
+        # 3 / 5 kernels: the plain multi-pass pipelines; 7: long blocks (split column pass); more: Bluestein-type plans
+        return (n & (n - 1)) == 0 and info["n1"] > 1 and info["nkernel"] in (3, 5, 7)
 
     def _check_in(self, x):
         if tuple(x.shape[:1]) != (self.nsample,) or int(np.prod(x.shape[1:])) != self.nchan * self.npol:

@@ -541,11 +541,15 @@ __global__ __launch_bounds__(256) void k_bs_post_fft(const cf* __restrict__ conv
 // Q-point transforms on the P row blocks (block c, row d holds k1 = c + P*d).  The inverse mirrors it:
 // conj twiddle, inverse P-point DFT, after the blocks' inverse transforms.  In place.
 template <int P, int DIR>
-__global__ __launch_bounds__(256) void k_radix_p(cf* __restrict__ data, int64_t plane, int S, int64_t chunk, int N2, int N1) {
+__global__ __launch_bounds__(256) void k_radix_p(const cf* __restrict__ src, int64_t src_plane, cf* __restrict__ dst,
+                                                 int64_t dst_plane, int S, int64_t chunk, int N2, int N1, int64_t keep0,
+                                                 int64_t keep1) {
+    // src / dst may be the same planar array (in place) or different ones (series-major caller arrays);
+    // dst is indexed by time - keep0 and only times in [keep0, keep1) are written (crop of the inverse stage)
     const int64_t total = (int64_t)S * chunk;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = e / chunk, np = e - s * chunk;
-        cf* base = data + s * plane + np;
+        const cf* base = src + s * src_plane + np;
         cf v[P];
 #pragma unroll
         for (int a = 0; a < P; ++a) v[a] = base[(int64_t)a * chunk];
@@ -562,8 +566,12 @@ __global__ __launch_bounds__(256) void k_radix_p(cf* __restrict__ data, int64_t 
             w = make_double2(w.x * w1.x - w.y * w1.y, w.x * w1.y + w.y * w1.x);
         }
         if (DIR > 0) Dft<P, +1>::run(v);
+        cf* obase = dst + s * dst_plane - keep0;
 #pragma unroll
-        for (int a = 0; a < P; ++a) base[(int64_t)a * chunk] = v[a];
+        for (int a = 0; a < P; ++a) {
+            const int64_t t = (int64_t)a * chunk + np;
+            if (t >= keep0 && t < keep1) obase[t] = v[a];
+        }
     }
 }
 

@@ -230,12 +230,13 @@ static int launch_colq(int M, ColpParams prm, hipStream_t st) {
 }
 
 template <int DIR>
-static int launch_radix(int P, cf* data, int64_t plane, int S, int64_t N, int N2, int N1, hipStream_t st) {
+static int launch_radix(int P, const cf* src, int64_t src_plane, cf* dst, int64_t dst_plane, int S, int64_t N, int N2,
+                        int N1, int64_t keep0, int64_t keep1, hipStream_t st) {
     const int64_t chunk = N / P;
     int64_t blocks = ((int64_t)S * chunk + 255) / 256;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     switch (P) {
-#define X(pp) case pp: hipLaunchKernelGGL((k_radix_p<pp, DIR>), dim3((unsigned)blocks), dim3(256), 0, st, data, plane, S, chunk, N2, N1); break;
+#define X(pp) case pp: hipLaunchKernelGGL((k_radix_p<pp, DIR>), dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, dst, dst_plane, S, chunk, N2, N1, keep0, keep1); break;
         X(2) X(4) X(8) X(16)
 #undef X
         default: return fail(PBH_ERR_UNSUPPORTED, "radix-P stage: P must be 2, 4, 8 or 16");
@@ -536,14 +537,20 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                                     N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
-        if (in_sm) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
+        if (in_sm && p->P == 1) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
             cp1.ld = in;
             cp1.ld_plane = io.in_pitch;
         }
         if (P > 1) {
             cp1.P = P;
-            if (!fuse_radix)
-                steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_radix<-1>(P, work, N, S, N, N2, N1, st); }});
+            if (!fuse_radix) {
+                // a series-major input is read by the radix stage (out of place into the workspace), not by the column pass
+                const cf* rsrc = in_sm ? in : work;
+                const int64_t rplane = in_sm ? io.in_pitch : N;
+                steps.push_back({"k_radix_fwd", [=](hipStream_t st) {
+                    return launch_radix<-1>(P, rsrc, rplane, work, N, S, N, N2, N1, 0, N, st);
+                }});
+            }
         }
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
             return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
@@ -560,7 +567,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
         ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
-        if (out_sm && !tail.out) {   // pass 3 writes the caller's series-major output directly, cropped
+        if (out_sm && !tail.out && p->P == 1) {   // pass 3 writes the caller's series-major output directly, cropped
             cp3.ld = work;
             cp3.ld_plane = N;
             cp3.data = out;
@@ -576,8 +583,18 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             return colp ? launch_colq<OP_TW_INV>(Q, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
         const bool fuse_out = fuse_radix && !tail.out;   // the detect tail reads time-ordered planar data
-        if (P > 1 && !fuse_out)
-            steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_radix<+1>(P, work, N, S, N, N2, N1, st); }});
+        if (P > 1 && !fuse_out) {
+            if (out_sm && !tail.out) {   // the inverse stage writes the caller's series-major output, cropped
+                const int64_t opitch = io.out_pitch;
+                steps.push_back({"k_radix_inv", [=](hipStream_t st) {
+                    return launch_radix<+1>(P, work, N, out, opitch, S, N, N2, N1, start, stop, st);
+                }});
+            } else {
+                steps.push_back({"k_radix_inv", [=](hipStream_t st) {
+                    return launch_radix<+1>(P, work, N, work, N, S, N, N2, N1, 0, N, st);
+                }});
+            }
+        }
         if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
@@ -1373,7 +1390,7 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     HIPCHECK(hipSetDevice(p->device));
     if (nout <= 0) return PBH_OK;
     const bool any_sm = in_layout == PBH_LAYOUT_SERIES_MAJOR || out_layout == PBH_LAYOUT_SERIES_MAJOR;
-    if (any_sm && (p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+    if (any_sm && (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                    p->N >= (1LL << 31)))
         return fail(PBH_ERR_UNSUPPORTED, "series-major I/O needs a multi-pass power-of-two plan (nsample > one tile)");
     IoLayout io;
@@ -1503,7 +1520,7 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
     if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
     if (in_layout == PBH_LAYOUT_SERIES_MAJOR) {
         if (in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
-        if (p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+        if (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
             p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
             p->nchan > 65535)
             return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan and nscrunch % 64 == 0");
