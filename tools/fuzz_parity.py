@@ -51,6 +51,19 @@ while time.time() - t0 < budget:
         y = np.asarray(pb.coherent_dedispersion(zz, pb.DM(dm), variant=variant).data)
     except NotImplementedError:
         continue
+    # now and then also the detect tail (fused when nscrunch % 64 == 0 on multi-pass planar plans)
+    if npol == 2 and rng.random() < 0.3 and stop - start > 4096:
+        k = int(rng.choice([1, 48, 64, 256]))
+        dmode = str(rng.choice(["I", "linear", "intensity"]))
+        got, s0 = pb.dedisperse_detect(zz, pb.DM(dm), mode=dmode, nscrunch=k)
+        ref = orc.to_intensity(yr) if dmode == "intensity" else orc.to_stokes(yr, "linear")
+        if dmode == "I":
+            ref = ref[:, :, 0]
+        ref = orc.scrunch(ref, k)
+        derr = np.abs(np.asarray(got) - ref).max() / max(np.abs(ref).max(), 1e-30)
+        if s0 != start or np.asarray(got).shape != ref.shape or not derr < (1e-4 if dtype == np.complex64 else 1e-7):
+            n_bad += 1
+            print(f"BAD detect n={n} nchan={nchan} {dmode} k={k} {mode} err={derr:.3e}", flush=True)
     err = np.linalg.norm(y - yr) / max(np.linalg.norm(yr), 1e-30)
     # complex128: the bound is set by last-bit flips of the complex64-rounded chirp (tests/test_gpu_parity.py), which
     # grow with the size of the float64 phase (high DM x wide channels): a few 1e-9
