@@ -68,12 +68,31 @@ def cpu_baseline():
     t0 = time.perf_counter()
     orc.coherent_dedispersion(x, DM, sr, CENTER_HZ, chirp=chirp, workers=ncores)
     tall = time.perf_counter() - t0
+    # (B) dask-equivalent: one task per (chan, pol) series on a thread pool, each a
+    # single-threaded scipy.fft -- what rechunk() + the threaded scheduler give the reference
+    from concurrent.futures import ThreadPoolExecutor
+    import scipy.fft as _sfft
+    nthreads = min(ncores, NCHAN_PER_GPU * NPOL)
+    start, stop = orc.crop_bounds(DM, n, NCHAN_PER_GPU, sr, CENTER_HZ, CENTER_HZ)
+
+    def one(cp):
+        c, p = cp
+        return _sfft.ifft(_sfft.fft(x[:, c, p]) * chirp[:, c].reshape(-1))[start:stop]
+
+    t0 = time.perf_counter()
+    try:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(one, [(c, p) for c in range(NCHAN_PER_GPU) for p in range(NPOL)]))
+        tpool = time.perf_counter() - t0
+    except Exception:
+        tpool = None
     nsamp = float(np.prod(shape))
     return {
         "value": nsamp / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": "oracle (numpy+scipy.fft, workers=None) on one full (2^24, 8, 2) c64 block, "
                   "DM 56.77, chirp precomputed; %.2f s" % t1,
         "all_cores": {"value": nsamp / tall / 1e6, "cores": ncores, "seconds": tall},
+        "series_thread_pool": None if tpool is None else {"value": nsamp / tpool / 1e6, "cores": nthreads, "seconds": tpool},
         "chirp_seconds": t_chirp, "host_cpus": ncores,
     }
 

@@ -15,7 +15,7 @@ from .. import units as u
 from ..core import BasebandSignal
 from ..device import DeviceArray
 
-__all__ = ["time_shift", "freq_shift", "fast_len"]
+__all__ = ["time_shift", "freq_shift", "snippet", "fast_len"]
 
 
 def _per_series(arr, z):
@@ -124,3 +124,32 @@ def fast_len(z, /):
     """Crop a signal to the largest 7-smooth length <= len(z) (transforms.py:364-382)."""
     from ..utils import prev_fast_len
     return z[: prev_fast_len(len(z))]
+
+
+def snippet(z, /, t, n):
+    """Extract ``n`` samples of ``z`` starting at ``t`` (transforms.py:151-208).
+
+    ``t`` is a number of samples (int or float), a time Quantity relative to the start of the
+    signal, or a Time.  A start that is not a whole number of samples is reached by the HIP
+    ``time_shift`` (phase gradient in the Fourier domain, cropped), as in the reference.
+    """
+    import operator
+    from ..time import Time
+    if (n := operator.index(n)) < 0:
+        raise ValueError("n must be a non-negative integer.")
+    if isinstance(t, Time):
+        if z.start_time is None:
+            raise ValueError("t is a Time object, but signal has no start time.")
+        t = (t - z.start_time).to(u.s)
+    if hasattr(t, "unit") and hasattr(t, "to_value"):
+        t = (t * z.sample_rate).to_value(u.one)
+    if np.ndim(t) != 0:
+        raise ValueError("t must be a scalar.")
+    if (t < 0) or (len(z) < t + n):
+        raise ValueError("Requested snippet goes out of bounds.")
+    if (i := int(t)) < t:
+        shift = i - t
+        new_start = None if z.start_time is None else z.start_time - shift * z.dt
+        shifted = time_shift(z, shift, crop=True).data
+        z = type(z).like(z, shifted, start_time=new_start)
+    return z[i:i + n]

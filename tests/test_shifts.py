@@ -150,3 +150,44 @@ class TestFreqShift:
             pb.freq_shift(pb.Signal(x, sample_rate=1 * u.MHz), 1 * u.kHz)
         with pytest.raises(ValueError):
             pb.freq_shift(z, 5.0)
+
+
+@pytest.mark.gpu
+class TestSnippet:
+    """reference tests/test_transforms.py:250-310."""
+
+    @pytest.mark.parametrize("N", [1024, 1023])
+    @pytest.mark.parametrize("with_start", [True, False])
+    def test_correctness(self, N, with_start):
+        from pulsarbat_amd.time import Time
+        start_time = Time.now() if with_start else None
+        for sr in [1 * u.Hz, 10 * u.Hz]:
+            for t0 in [20.0, 10.5, 15.9]:
+                x = pb.Signal(impulse(N, t0), sample_rate=sr, start_time=start_time)
+                for n in [8, 16, 25]:
+                    ts = [t0, t0 * x.dt]
+                    if start_time is not None:
+                        ts.append(start_time + t0 * x.dt)
+                    for t in ts:
+                        y = pb.snippet(x, t, n)
+                        z = np.zeros_like(np.asarray(y.data))
+                        z[0] = 1
+                        assert np.allclose(np.asarray(y.data), z, atol=1e-8)
+                        assert x.sample_rate == y.sample_rate and len(y) == n
+                        if x.start_time is None:
+                            assert y.start_time is None
+                        else:
+                            assert Time.isclose(y.start_time, x.start_time + t0 * x.dt)
+
+    def test_errors(self):
+        from pulsarbat_amd.time import Time
+        z = pb.Signal(impulse(1024, 512), sample_rate=1 * u.Hz)
+        for t, n in [(-100, 100), (-100, -100), (1000, 50), (1000, -50), (2000, 20), (2000, -20)]:
+            with pytest.raises(ValueError):
+                pb.snippet(z, t, n)
+        with pytest.raises(TypeError):
+            pb.snippet(z, 0, np.arange(4))
+        with pytest.raises(ValueError):
+            pb.snippet(z, np.arange(10), 10)
+        with pytest.raises(ValueError):
+            pb.snippet(z, Time.now(), 10)
