@@ -15,7 +15,7 @@ from .. import units as u
 from ..core import BasebandSignal
 from ..device import DeviceArray
 
-__all__ = ["time_shift", "freq_shift", "snippet", "fast_len"]
+__all__ = ["signal_transform", "concatenate", "time_shift", "freq_shift", "snippet", "fast_len"]
 
 
 def _per_series(arr, z):
@@ -153,3 +153,91 @@ def snippet(z, /, t, n):
         shifted = time_shift(z, shift, crop=True).data
         z = type(z).like(z, shifted, start_time=new_start)
     return z[i:i + n]
+
+
+def signal_transform(func):
+    """Turn an array function ``func(x, **kwargs) -> array`` into a signal transform
+    (transforms.py:21-56, without the dask branch: device arrays are passed to ``func`` as they are).
+
+    The wrapper takes a Signal in place of the array and returns ``signal_type.like(signal, result,
+    **signal_kwargs)``; ``signal_type`` defaults to the input's type.
+    """
+    import functools
+    from ..core import Signal
+
+    @functools.wraps(func)
+    def wrapper(x, *args, signal_type=None, signal_kwargs=None, dask_kwargs=None, **kwargs):
+        cls = type(x) if signal_type is None else signal_type
+        if not (isinstance(cls, type) and issubclass(cls, Signal)):
+            raise TypeError("Signal type must be a subclass of pulsarbat.Signal!")
+        return cls.like(x, func(x.data, **kwargs), **(signal_kwargs or {}))
+
+    return wrapper
+
+
+def concatenate(signals, /, axis=0):
+    """Join contiguous signals along time (``axis`` 0 / "time") or another axis (1 / "freq" joins
+    frequency-contiguous RadioSignals) -- transforms.py:59-148.  This is what defines the expected
+    result of the streaming driver: ``concatenate([coherent_dedispersion(chunk_k, ...)])``.
+
+    Checks, as in the reference: one common type and sample rate; along time the start times must
+    follow one another; across another axis they must agree; RadioSignals need a common channel
+    bandwidth and, along frequency, adjacent channel grids.  numpy data is joined with numpy,
+    device data on the device.
+    """
+    from ..core import Signal, RadioSignal
+    from ..time import Time
+    signals = list(signals)
+    if not signals:
+        raise ValueError("Need at least one signal to concatenate.")
+    first = signals[0]
+    if not isinstance(first, Signal):
+        raise TypeError("Signals must be pulsarbat.Signal objects.")
+    if any(type(s) is not type(first) for s in signals):
+        raise TypeError("All signals must have same type!")
+    sr = first.sample_rate
+    if not all(u.isclose(sr, s.sample_rate) for s in signals):
+        raise ValueError("Signals must have the same sample_rate!")
+
+    along_time = axis in (0, "time")
+    start, offset = None, 0
+    for s in signals:
+        if s.start_time is not None:
+            expected_first = s.start_time - (offset / sr) if along_time else s.start_time
+            if start is None:
+                start = expected_first
+            elif not Time.isclose(start, expected_first):
+                raise ValueError("Signals not contiguous in time." if along_time
+                                 else "Signals have different start_time.")
+        if along_time:
+            offset += len(s)
+    kw = {"start_time": start}
+
+    if isinstance(first, RadioSignal):
+        cbw = first.chan_bw
+        if not all(u.isclose(cbw, s.chan_bw) for s in signals):
+            raise ValueError("RadioSignals must have the same chan_bw!")
+        if axis in (1, "freq"):
+            for lo, hi in zip(signals, signals[1:]):
+                if not u.isclose(hi.channel_freqs[0] - lo.channel_freqs[-1], cbw):
+                    raise ValueError("Signals not contiguous in frequency.")
+            f_lo, f_hi = first.channel_freqs[0], signals[-1].channel_freqs[-1]
+        else:
+            ref = u.to_value(first.channel_freqs, u.Hz)
+            for s in signals:
+                other = u.to_value(s.channel_freqs, u.Hz)
+                if np.shape(other) != np.shape(ref) or not np.allclose(other, ref):
+                    raise ValueError("Signals have different frequency channels.")
+            f_lo, f_hi = first.channel_freqs[0], first.channel_freqs[-1]
+        kw["center_freq"] = (f_lo + f_hi) / 2
+        kw["freq_align"] = "center"
+    elif axis == "freq":
+        raise TypeError("Signals must be pb.RadioSignal objects when axis is 'freq'.")
+
+    ax = 0 if along_time else (1 if axis == "freq" else int(axis))
+    if all(isinstance(s.data, DeviceArray) for s in signals):
+        import torch
+        data = DeviceArray(torch.cat([s.data.tensor for s in signals], dim=ax))
+    else:
+        data = np.concatenate([np.asarray(s.data) for s in signals], axis=ax)
+    return type(first).like(first, data, **kw)
