@@ -398,6 +398,14 @@ __device__ __forceinline__ void launder_all(cf* a, std::integer_sequence<int, I.
     (launder1(a[I]), ...);
 }
 
+// cache-policy bits of the streaming buffer accesses (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+#ifndef PBH_LOAD_AUX
+#define PBH_LOAD_AUX 0
+#endif
+#ifndef PBH_STORE_AUX
+#define PBH_STORE_AUX 0
+#endif
+
 // ---- buffer (SRD) addressing: wave-uniform base in SGPRs, 32-bit per-lane offset, scalar step ----
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -427,14 +435,14 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
 }
 #else
 __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
-    u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, PBH_LOAD_AUX);
     return make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
 }
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     u32x2 x;
     x.x = __float_as_uint(a.x);
     x.y = __float_as_uint(a.y);
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, PBH_STORE_AUX);
 }
 #endif
 
