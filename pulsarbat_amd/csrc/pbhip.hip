@@ -533,8 +533,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         const int P = p->P, Q = N1 / P;
-        const bool colp = P > 1 || ((colp_mode() != 0 || in_sm || out_sm) && Q <= kTilePoints &&
-                                    N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
+        // (very short column transforms, Q < 64, leave the persistent kernel no butterflies to hide its memory
+        //  traffic behind -- and its inverse form spills there: one-tile workgroups are as fast or faster)
+        const bool colp = P > 1 || in_sm || out_sm ||
+                          (colp_mode() != 0 && Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
         if (in_sm && p->P == 1) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
