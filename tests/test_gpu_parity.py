@@ -488,9 +488,13 @@ def test_series_major_io(shape, dm, dtype):
     assert y2.tensor.is_contiguous() and series_errors(y2, yr)[0] < tol
     y3 = plan.dedisperse(zd.data, out_layout="series")
     assert y3.series_major_pitch() is not None and series_errors(y3, yr)[0] < tol
-    # bit-identical to the sample-major path (same kernels in the middle, same arithmetic)
+    # same kernels in the middle, same arithmetic: bit-identical to the sample-major path whenever that path
+    # uses the persistent column kernel too (column transforms of 64 points and more)
     y0 = plan.dedisperse(zd.data)
-    assert np.array_equal(np.asarray(y0), np.asarray(y3))
+    if plan.info["n1"] >= 64:
+        assert np.array_equal(np.asarray(y0), np.asarray(y3))
+    else:
+        assert series_errors(y0, np.asarray(y3))[0] < (2e-6 if dtype == np.complex64 else 1e-13)
 
 
 @pytest.mark.gpu
@@ -539,7 +543,8 @@ def test_series_major_dedisperse_detect(mode, nscrunch):
     a, s0 = pb.dedisperse_detect(z, pb.DM(15.0), mode=mode, nscrunch=nscrunch)
     b, s1 = pb.dedisperse_detect(zs, pb.DM(15.0), mode=mode, nscrunch=nscrunch)
     assert s0 == s1 and a.shape == b.shape
-    assert np.array_equal(np.asarray(a), np.asarray(b))
+    # (N1 = 8 here: the sample-major call uses the one-tile column kernel, the series-major one the persistent kernel)
+    assert np.allclose(np.asarray(a), np.asarray(b), rtol=2e-5, atol=2e-5 * np.abs(np.asarray(a)).max())
 
 
 @pytest.mark.gpu
