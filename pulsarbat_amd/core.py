@@ -262,10 +262,17 @@ class Signal(np.lib.mixins.NDArrayOperatorsMixin):
         """Signal with data left where it is (device-resident stays resident)."""
         return type(self).like(self, self.data)
 
-    def to_device(self, device=None):
-        """Signal whose data lives in HBM as a :class:`DeviceArray`."""
+    def to_device(self, device=None, series_major=False):
+        """Signal whose data lives in HBM as a :class:`DeviceArray`.
+
+        ``series_major=True`` stores it with time as the fastest axis (same shape, other strides): the
+        layout the column passes of ``coherent_dedispersion`` work in, so device-resident pipelines that
+        keep their arrays this way skip the two layout passes."""
         from .device import DeviceArray
-        return type(self).like(self, DeviceArray.from_host(self.data, device=device))
+        d = DeviceArray.from_host(self.data, device=device)
+        if series_major and d.ndim >= 2:
+            d = d.to_series_major()
+        return type(self).like(self, d)
 
     @classmethod
     def like(cls, obj, z=None, /, **kwargs):

@@ -473,7 +473,7 @@ def test_series_major_io(shape, dm, dtype):
     yr, start, stop = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
     tol = RTOL_L2 if dtype == np.complex64 else RTOL_F64
     zd = z.to_device()
-    zs = type(z).like(z, zd.data.to_series_major())
+    zs = z.to_device(series_major=True)
     assert zs.data.series_major_pitch() is not None and not zs.data.tensor.is_contiguous()
     assert np.array_equal(np.asarray(zs.data), x)
     # series-major in -> series-major out
