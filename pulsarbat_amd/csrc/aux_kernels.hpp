@@ -127,6 +127,78 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
     }
 }
 
+// ---- layout passes for many series (channelised blocks: S = hundreds to thousands) ---------------------------
+// With S series a time sample is S*8 bytes of input; tiles of "4096/S time samples x all series" would write
+// only a few elements per series.  These kernels tile BOTH axes instead: a workgroup transposes SB series x TB
+// time samples (32 KiB) through LDS, reading and writing 512-byte runs on both sides.  Any S (f32: even), any N.
+template <int SB, int TB>
+__global__ __launch_bounds__(256) void k_deint_blk(const cf* __restrict__ in, cf* __restrict__ out, int64_t N, int S,
+                                                   int64_t plane) {
+    constexpr int VE = 16 / (int)sizeof(cf);          // elements per 16-byte vector (2 for complex64, 1 for complex128)
+    constexpr int LD = TB + 1;
+    constexpr int NV = SB * TB / VE / 256;
+    typedef float vec16 __attribute__((ext_vector_type(4)));
+    __shared__ cf lds[SB * LD];
+    const int64_t n0 = (int64_t)blockIdx.x * TB;
+    const int s0 = blockIdx.y * SB;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int t = q / (SB / VE), sv = q % (SB / VE);
+        const int s = s0 + sv * VE;
+        if (n0 + t < N && s < S) {
+            union { vec16 v; cf c[VE]; } x;
+            x.v = *reinterpret_cast<const vec16*>(in + (n0 + t) * S + s);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) lds[(sv * VE + e) * LD + t] = x.c[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int sl = q / (TB / VE), t = (q % (TB / VE)) * VE;
+        if (s0 + sl < S && n0 + t < N) {
+            union { vec16 v; cf c[VE]; } x;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) x.c[e] = lds[sl * LD + t + e];
+            *reinterpret_cast<vec16*>(out + (int64_t)(s0 + sl) * plane + n0 + t) = x.v;
+        }
+    }
+}
+
+// planar [s][t] -> (stop-start, S) interleaved, keeping t in [start, stop)
+template <int SB, int TB>
+__global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf* __restrict__ out, int64_t start,
+                                                   int64_t stop, int S, int64_t plane) {
+    constexpr int VE = 16 / (int)sizeof(cf);
+    constexpr int LD = TB + 1;
+    constexpr int NE = SB * TB / 256, NV = SB * TB / VE / 256;
+    typedef float vec16 __attribute__((ext_vector_type(4)));
+    __shared__ cf lds[SB * LD];
+    const int64_t t0 = start + (int64_t)blockIdx.x * TB;
+    const int s0 = blockIdx.y * SB;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {   // element loads: t0 need not be 16-byte aligned
+        const int q = threadIdx.x + 256 * j;
+        const int sl = q / TB, t = q % TB;
+        if (s0 + sl < S && t0 + t < stop) lds[sl * LD + t] = in[(int64_t)(s0 + sl) * plane + t0 + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int t = q / (SB / VE), sv = q % (SB / VE);
+        const int s = s0 + sv * VE;
+        if (t0 + t < stop && s < S) {
+            union { vec16 v; cf c[VE]; } x;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) x.c[e] = lds[(sv * VE + e) * LD + t];
+            *reinterpret_cast<vec16*>(out + (t0 - start + t) * S + s) = x.v;
+        }
+    }
+}
+
 #ifndef PBH_F64
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the

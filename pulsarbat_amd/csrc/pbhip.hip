@@ -339,7 +339,20 @@ static int tr_rows(int S) {
     return tn < 1 ? 1 : tn;
 }
 
+// many series: tile both axes (k_deint_blk / k_reint_blk).  complex64 needs 16-byte alignment of (n*S + s) pairs.
+static bool blk_layout_ok(int S, int64_t N) {
+    constexpr int VE = 16 / (int)sizeof(cf);
+    return S > 128 && S % VE == 0 && N % VE == 0;
+}
+constexpr int kBlkS = 64, kBlkT = 16 * 1024 * 2 / (int)sizeof(cf) / 64;   // 64 series x 64 (c64) or 32 (c128) samples = 32 KiB
+
 static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
+    if (blk_layout_ok(S, N)) {
+        hipLaunchKernelGGL((k_deint_blk<kBlkS, kBlkT>), dim3((unsigned)((N + kBlkT - 1) / kBlkT), (unsigned)((S + kBlkS - 1) / kBlkS)),
+                           dim3(256), 0, st, in, work, N, S, N);
+        HIPCHECK(hipGetLastError());
+        return PBH_OK;
+    }
     const int TN = tr_rows(S);
 #ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
@@ -362,6 +375,12 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStre
 static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane,
                                hipStream_t st) {
     if (stop <= start) return PBH_OK;
+    if (blk_layout_ok(S, plane)) {
+        hipLaunchKernelGGL((k_reint_blk<kBlkS, kBlkT>), dim3((unsigned)((stop - start + kBlkT - 1) / kBlkT), (unsigned)((S + kBlkS - 1) / kBlkS)),
+                           dim3(256), 0, st, work, out, start, stop, S, plane);
+        HIPCHECK(hipGetLastError());
+        return PBH_OK;
+    }
     const int TN = tr_rows(S);
     int64_t done = 0;
 #ifndef PBH_F64
