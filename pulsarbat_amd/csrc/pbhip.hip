@@ -537,6 +537,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     const int N1 = p->N1, N2 = p->N2;
     cf* work = p->work;
 
+    // one series: the (nsample, 1) block is its own series-major form -- no layout passes are needed at all
+    // (matters for long blocks, where the 3-pass variant is not available)
+    if (S == 1 && p->P > 1 && !tail.out && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR && io.out_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
+        io.in_layout = io.out_layout = PBH_LAYOUT_SERIES_MAJOR;
+        io.in_pitch = p->N;
+        io.out_pitch = p->stop - p->start;
+    }
     const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
     if (variant == PBH_VARIANT_PLANAR5 || in_sm || out_sm) {
         const int64_t N = p->N, start = p->start, stop = p->stop;
