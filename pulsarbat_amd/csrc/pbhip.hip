@@ -339,19 +339,46 @@ static int tr_rows(int S) {
     return tn < 1 ? 1 : tn;
 }
 
-// many series: tile both axes (k_deint_blk / k_reint_blk).  complex64 needs 16-byte alignment of (n*S + s) pairs.
-static bool blk_layout_ok(int S, int64_t N) {
+// Two-axis tiles (k_deint_blk / k_reint_blk): SB series x TB samples = 32 KiB per workgroup.  Used for many
+// series (S > 128: SB = 64, several series blocks) and for series counts the power-of-two row transposes do
+// not cover (SB = next power of two >= S, lanes beyond S idle).  complex64 needs 16-byte aligned (n*S + s) pairs.
+constexpr int kBlkElems = 32 * 1024 / (int)sizeof(cf);
+static int blk_series(int S, int64_t N) {
     constexpr int VE = 16 / (int)sizeof(cf);
-    return S > 128 && S % VE == 0 && N % VE == 0;
+    if (S % VE != 0 || N % VE != 0 || S < 2) return 0;
+#ifndef PBH_F64
+    if ((S & (S - 1)) == 0 && S <= 128) return 0;   // k_*_p2 row transposes
+#endif
+    static const bool on = [] { const char* e = getenv("PBH_BLK_LAYOUT"); return e ? atoi(e) != 0 : true; }();
+    if (!on && S <= 128) return 0;
+    int sb = 4;
+    while (sb < S && sb < 64) sb <<= 1;
+    return sb;
 }
-constexpr int kBlkS = 64, kBlkT = 16 * 1024 * 2 / (int)sizeof(cf) / 64;   // 64 series x 64 (c64) or 32 (c128) samples = 32 KiB
+template <int SB>
+static int launch_deint_blk(const cf* in, cf* work, int64_t N, int S, int64_t plane, hipStream_t st) {
+    constexpr int TB = kBlkElems / SB;
+    hipLaunchKernelGGL((k_deint_blk<SB, TB>), dim3((unsigned)((N + TB - 1) / TB), (unsigned)((S + SB - 1) / SB)), dim3(256), 0, st,
+                       in, work, N, S, plane);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+template <int SB>
+static int launch_reint_blk(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane, hipStream_t st) {
+    constexpr int TB = kBlkElems / SB;
+    hipLaunchKernelGGL((k_reint_blk<SB, TB>), dim3((unsigned)((stop - start + TB - 1) / TB), (unsigned)((S + SB - 1) / SB)), dim3(256), 0,
+                       st, work, out, start, stop, S, plane);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
 
 static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
-    if (blk_layout_ok(S, N)) {
-        hipLaunchKernelGGL((k_deint_blk<kBlkS, kBlkT>), dim3((unsigned)((N + kBlkT - 1) / kBlkT), (unsigned)((S + kBlkS - 1) / kBlkS)),
-                           dim3(256), 0, st, in, work, N, S, N);
-        HIPCHECK(hipGetLastError());
-        return PBH_OK;
+    switch (blk_series(S, N)) {
+        case 4: return launch_deint_blk<4>(in, work, N, S, N, st);
+        case 8: return launch_deint_blk<8>(in, work, N, S, N, st);
+        case 16: return launch_deint_blk<16>(in, work, N, S, N, st);
+        case 32: return launch_deint_blk<32>(in, work, N, S, N, st);
+        case 64: return launch_deint_blk<64>(in, work, N, S, N, st);
     }
     const int TN = tr_rows(S);
 #ifndef PBH_F64
@@ -375,11 +402,12 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStre
 static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane,
                                hipStream_t st) {
     if (stop <= start) return PBH_OK;
-    if (blk_layout_ok(S, plane)) {
-        hipLaunchKernelGGL((k_reint_blk<kBlkS, kBlkT>), dim3((unsigned)((stop - start + kBlkT - 1) / kBlkT), (unsigned)((S + kBlkS - 1) / kBlkS)),
-                           dim3(256), 0, st, work, out, start, stop, S, plane);
-        HIPCHECK(hipGetLastError());
-        return PBH_OK;
+    switch (blk_series(S, plane)) {
+        case 4: return launch_reint_blk<4>(work, out, start, stop, S, plane, st);
+        case 8: return launch_reint_blk<8>(work, out, start, stop, S, plane, st);
+        case 16: return launch_reint_blk<16>(work, out, start, stop, S, plane, st);
+        case 32: return launch_reint_blk<32>(work, out, start, stop, S, plane, st);
+        case 64: return launch_reint_blk<64>(work, out, start, stop, S, plane, st);
     }
     const int TN = tr_rows(S);
     int64_t done = 0;
