@@ -136,7 +136,10 @@ static int resolved_variant(const pbh_plan* p) {
     if (p->variant != PBH_VARIANT_AUTO) return p->variant;
     // direct3 touches full 128-B lines only when a 16-column tile spans whole time samples of few
     // series; with many interleaved series its planar side degenerates to 8-byte pieces
-    return p->S <= 2 ? PBH_VARIANT_DIRECT3 : PBH_VARIANT_PLANAR5;
+    // (beyond N1 = 2^tile/16 its 16-column tile is no longer whole lines on the interleaved side either: with two
+    //  series at N = 2^25 the planar pipeline is faster, 52 vs 45 Gsamples/s)
+    if (p->S == 1) return PBH_VARIANT_DIRECT3;
+    return (p->S <= 2 && p->N1 * 16 <= kTilePoints) ? PBH_VARIANT_DIRECT3 : PBH_VARIANT_PLANAR5;
 }
 
 // ---- kernel dispatch by FFT length ---------------------------------------------------------------------------
