@@ -250,7 +250,7 @@ class Plan:
         """True when pbh_dedisperse_layout accepts series-major ends for this plan."""
         n = self.nsample
         info = self.info
-        # 3 / 5 kernels: the plain multi-pass pipelines; 7: long blocks (split column pass); more: Bluestein-type plans
+        # 3 / 5 / 7 kernels: multi-pass pipelines (7: long blocks with a stand-alone radix stage); 1 + ...: other lengths
         return (n & (n - 1)) == 0 and info["n1"] > 1 and info["nkernel"] in (3, 5, 7)
 
     def _check_in(self, x):

@@ -1150,7 +1150,9 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->n1 = p->N1;
     info->n2 = p->N2;
     info->variant = resolved_variant(p);
-    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) + (p->P > 1 ? 2 : 0);
+    // (long blocks: +2 for the stand-alone radix-P stage unless it is folded into the layout passes)
+    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) +
+                                         ((p->P > 1 && !radix_layout_ok(p->S, p->P, p->N, p->N2)) ? 2 : 0);
     if (p->bsL && p->cfilt) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->cfilt, &sub);

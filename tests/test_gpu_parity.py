@@ -611,7 +611,7 @@ def test_split_column_transform(small_qmax, shape, dm, dtype, qmax, nk):
     tol = RTOL_L2 if dtype == np.complex64 else RTOL_F64
     from pulsarbat_amd.transforms.dedispersion import _prepare
     plan, xin, _, _ = _prepare(z.to_device(), pb.DM(dm), None, None, "auto")
-    assert plan.info["nkernel"] == nk
+    assert plan.info["nkernel"] in (nk, nk - 2)   # 5 when the radix stage is folded into the layout passes
     y = pb.coherent_dedispersion(z.to_device(), pb.DM(dm))
     assert y.shape == yr.shape and series_errors(y, yr)[0] < tol
     # user chirp (uploaded in the reference's order), chirp download, and the fused detect tail use the same row order

@@ -30,7 +30,7 @@ def run(n, nchan=8, npol=2, dm=56.77, band=400e6, center=1.4e9, check=True):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     err = None
     if check:
-        c, p = 3, 1
+        c, p = min(3, nchan - 1), min(1, npol - 1)
         xs = x.tensor[:, c, p].cpu().numpy().reshape(-1, 1)
         import scipy.fft
         chirp = orc.transfer_function(dm, n, 1 / sr, freqs[c], center).reshape(-1, 1)
