@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
 // blocks are back to five passes.  E elements per chunk tile, chosen so a thread holds <= 32 float4.
 template <int P>
 struct RadixTile {
-    static constexpr int E = P <= 4 ? 4096 : 4096 * 4 / P;
+    static constexpr int E = P <= 4 ? 4096 : (P <= 8 ? 2048 : 1024);
 };
 template <int P>
 __device__ __forceinline__ void radix_twiddles(cf (&tw)[P], int64_t b, int N1, int dir) {

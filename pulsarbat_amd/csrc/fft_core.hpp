@@ -154,6 +154,57 @@ struct Dft<32, DIR> {
     static __device__ __forceinline__ void run(cf (&v)[32], TK tick) { dft_composite<4, 8, DIR, TK>(v, tick); }
 };
 
+// ---- small odd DFTs (3, 5, 7 points): the odd factor of lengths m * 2^k, done across the chunks of the
+// radix-P stage (aux_kernels.hpp: k_radix_p, k_deint_radix).  Direct O(P^2) form with literal roots of unity:
+// P complex multiplies per element in passes that are bound by memory anyway.
+template <int P>
+struct OddRoots;
+template <>
+struct OddRoots<3> {
+    static __device__ __forceinline__ real c(int j) { constexpr real t[3] = {RC(1.0), RC(-0.49999999999999978), RC(-0.50000000000000044)}; return t[j]; }
+    static __device__ __forceinline__ real s(int j) { constexpr real t[3] = {RC(0.0), RC(0.86602540378443871), RC(-0.86602540378443837)}; return t[j]; }
+};
+template <>
+struct OddRoots<5> {
+    static __device__ __forceinline__ real c(int j) { constexpr real t[5] = {RC(1.0), RC(0.30901699437494745), RC(-0.80901699437494734), RC(-0.80901699437494756), RC(0.30901699437494723)}; return t[j]; }
+    static __device__ __forceinline__ real s(int j) { constexpr real t[5] = {RC(0.0), RC(0.95105651629515353), RC(0.58778525229247325), RC(-0.58778525229247303), RC(-0.95105651629515364)}; return t[j]; }
+};
+template <>
+struct OddRoots<7> {
+    static __device__ __forceinline__ real c(int j) { constexpr real t[7] = {RC(1.0), RC(0.62348980185873359), RC(-0.22252093395631434), RC(-0.90096886790241903), RC(-0.90096886790241915), RC(-0.22252093395631459), RC(0.62348980185873337)}; return t[j]; }
+    static __device__ __forceinline__ real s(int j) { constexpr real t[7] = {RC(0.0), RC(0.7818314824680298), RC(0.97492791218182362), RC(0.43388373911755823), RC(-0.43388373911755801), RC(-0.97492791218182362), RC(-0.78183148246802991)}; return t[j]; }
+};
+template <int P, int DIR>
+__device__ __forceinline__ void dft_odd(cf (&v)[P]) {
+    cf o[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        cf acc = v[0];
+#pragma unroll
+        for (int a = 1; a < P; ++a) {
+            const int j = (a * c) % P;   // compile-time after unrolling
+            const real wr = OddRoots<P>::c(j), wi = DIR < 0 ? -OddRoots<P>::s(j) : OddRoots<P>::s(j);
+            acc.x += v[a].x * wr - v[a].y * wi;
+            acc.y += v[a].x * wi + v[a].y * wr;
+        }
+        o[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < P; ++c) v[c] = o[c];
+}
+template <int DIR>
+struct Dft<3, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[3]) { dft_odd<3, DIR>(v); }
+};
+template <int DIR>
+struct Dft<5, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[5]) { dft_odd<5, DIR>(v); }
+};
+template <int DIR>
+struct Dft<7, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[7]) { dft_odd<7, DIR>(v); }
+};
+
 // ---- stage plan ------------------------------------------------------------------------------
 // Stages for length M with R points per thread: radix R while at least R remain, then one
 // stage of the remainder.
@@ -451,13 +502,15 @@ struct BigTwiddle {
     const double2* hi;  // W_N^{m << shift}
     const double2* lo;  // W_N^{l}, l < 2^shift
     int shift;
-    int64_t mask;  // N - 1
+    int64_t mask;  // N - 1 (N a power of two)
+    int64_t nmod = 0;  // N when it is NOT a power of two (m * 2^k plans): exponents are reduced with % instead of &
 };
+__device__ __forceinline__ int64_t tw_reduce(const BigTwiddle& t, int64_t p) { return t.nmod ? p % t.nmod : (p & t.mask); }
 __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ double2 big_tw(const BigTwiddle& t, int64_t p) {
-    p &= t.mask;
+    p = tw_reduce(t, p);
     double2 a = t.hi[p >> t.shift];
     double2 b = t.lo[p & ((1LL << t.shift) - 1)];
     return zmul(a, b);

@@ -227,8 +227,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     };
     // inter-pass twiddle W_N^{n2 k1}, k1 = c + P*(tau + i*MR): base and step of the float64 recurrence
     auto load_tables = [&](int n2, int c, double2& bh, double2& bl, double2& sh, double2& sl) {
-        const int64_t pb = ((int64_t)n2 * (c + (int64_t)p.P * tau)) & p.tw.mask;
-        const int64_t ps = ((int64_t)n2 * p.P * MR) & p.tw.mask;
+        const int64_t pb = tw_reduce(p.tw, (int64_t)n2 * (c + (int64_t)p.P * tau));
+        const int64_t ps = tw_reduce(p.tw, (int64_t)n2 * p.P * MR);
         bh = p.tw.hi[pb >> shift];
         bl = p.tw.lo[pb & lomask];
         sh = p.tw.hi[ps >> shift];

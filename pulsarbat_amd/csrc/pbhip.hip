@@ -74,6 +74,38 @@ static int ilog2(int64_t x) {
     return l;
 }
 static bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+static int64_t next_pow2_at_least(int64_t x) {
+    int64_t L = PBH_R;
+    while (L < x) L <<= 1;
+    return L;
+}
+// Lengths m * 2^k with m in {3, 5, 7} run natively: the odd factor becomes the radix-P stage of the split
+// column transform (k_radix_p / k_deint_radix), 2^k = Q * 2^tile with PBH_R <= Q <= one-line-wide tiles.
+// PBH_ODD=0 turns this off (such lengths then go through the convolution plan like any other).
+static int native_odd_factor(int64_t n) {
+    static const bool on = [] { const char* e = getenv("PBH_ODD"); return e ? atoi(e) != 0 : true; }();
+    if (!on) return 0;
+    const int64_t qmax = (int64_t)kTilePoints * (int64_t)sizeof(cf) / 128;
+    for (int m : {3, 5, 7}) {
+        if (n % m) continue;
+        const int64_t two = n / m;
+        if (!is_pow2(two) || two % kTilePoints) continue;
+        const int64_t q = two / kTilePoints;
+        if (q >= PBH_R && q <= qmax) return m;
+    }
+    return 0;
+}
+// Shortest native length >= x for the convolution plan of an arbitrary-length transform: 2^k or m * 2^k.
+static int64_t convolution_length(int64_t x) {
+    int64_t best = next_pow2_at_least(x);
+    for (int m : {3, 5, 7}) {
+        int64_t two = kTilePoints * (int64_t)PBH_R;
+        while (m * two < x) two <<= 1;
+        const int64_t L = m * two;
+        if (L < best && native_odd_factor(L) == m) best = L;
+    }
+    return best;
+}
 
 // ---- plan ------------------------------------------------------------------------------------------------
 struct Step {
@@ -240,9 +272,9 @@ static int launch_radix(int P, const cf* src, int64_t src_plane, cf* dst, int64_
     if (blocks > (1 << 20)) blocks = 1 << 20;
     switch (P) {
 #define X(pp) case pp: hipLaunchKernelGGL((k_radix_p<pp, DIR>), dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, dst, dst_plane, S, chunk, N2, N1, keep0, keep1); break;
-        X(2) X(4) X(8) X(16)
+        X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
-        default: return fail(PBH_ERR_UNSUPPORTED, "radix-P stage: P must be 2, 4, 8 or 16");
+        default: return fail(PBH_ERR_UNSUPPORTED, "radix-P stage: P must be 2, 3, 4, 5, 7, 8 or 16");
     }
     HIPCHECK(hipGetLastError());
     return PBH_OK;
@@ -444,8 +476,9 @@ static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
     return false;
 #else
     static const bool on = [] { const char* e = getenv("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
-    if (!on || P < 2 || P > 16 || S < 2 || S > 128 || (S & (S - 1)) != 0) return false;
-    const int E = P <= 4 ? 4096 : 4096 * 4 / P, TN = E / S;
+    if (!on || S < 2 || S > 128 || (S & (S - 1)) != 0) return false;
+    if (P != 2 && P != 3 && P != 4 && P != 5 && P != 7 && P != 8 && P != 16) return false;
+    const int E = P <= 4 ? 4096 : (P <= 8 ? 2048 : 1024), TN = E / S;
     return TN >= 16 && (N / P) % TN == 0 && N2 % TN == 0;
 #endif
 }
@@ -455,7 +488,7 @@ static int launch_deint_radix_s(int P, const cf* in, cf* work, int64_t N, int N2
     const int64_t chunk = N / P;
     switch (P) {
 #define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1); break;
-        X(2) X(4) X(8) X(16)
+        X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
     }
     HIPCHECK(hipGetLastError());
@@ -467,7 +500,7 @@ static int launch_reint_radix_s(int P, const cf* work, cf* out, int64_t N, int N
     const int64_t chunk = N / P;
     switch (P) {
 #define X(pp) case pp: hipLaunchKernelGGL((k_reint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, work, out, chunk, N, N2, N1, start, stop); break;
-        X(2) X(4) X(8) X(16)
+        X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
     }
     HIPCHECK(hipGetLastError());
@@ -562,6 +595,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     }
     const int variant = resolved_variant(p);
     BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, p->N - 1};
+    tw.nmod = is_pow2(p->N) ? 0 : p->N;
     const int64_t ncols = (int64_t)S * p->N2;
     ColSide planar{LAYOUT_PLANAR, p->N, p->N2};
     ColSide inter{LAYOUT_INTERLEAVED, 0, (int64_t)p->N2 * S};
@@ -849,6 +883,34 @@ extern "C" int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int 
 // Bluestein set-up: sub-plan over the ring length, b table, and the spectrum of the wrapped kernel
 // conj(b) written straight into the sub-plan's chirp buffer in plan order (column pass + forward
 // row pass leave bin k1 + N1 k2 at position k1*N2 + k2, which is the chirp layout).
+// Forward transform, in plan (row) order and in place, of `nplanes` planar length-L arrays stored where the
+// sub-plan q keeps its chirp: the spectrum a convolution plan multiplies by.  Split plans (q->P > 1, which
+// includes every m * 2^k length) go through their own radix-P stage and row blocks, so the rows come out in
+// the split order; unsplit ones through the one-tile column kernel.  `scratch` holds nplanes * L elements.
+static int spectrum_in_plan_order(pbh_plan* q, int nplanes, cf* scratch, hipStream_t st) {
+    const int64_t L = q->N;
+    BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
+    tw.nmod = is_pow2(L) ? 0 : L;
+    if (q->P > 1 && q->N2 % (kTilePoints / (q->N1 / q->P)) == 0) {
+        PBHCHECK(launch_radix<-1>(q->P, q->chirp, L, q->chirp, L, nplanes, L, q->N2, q->N1, 0, L, st));
+        ColpParams cp{q->chirp, L, nplanes, q->N2, tw, q->tw16k, 0, L, 0, nullptr};
+        cp.P = q->P;
+        PBHCHECK(launch_colq<OP_FWD_TW>(q->N1 / q->P, cp, st));
+        return launch_rowfft(q->N2, q->chirp, q->tw16k, (int64_t)nplanes * q->N1, st);
+    }
+    ColSide planar{LAYOUT_PLANAR, L, q->N2};
+    ColParams c1{q->chirp, q->chirp, planar, planar, LAYOUT_PLANAR, 0, 0, nplanes, q->N2, (int64_t)nplanes * q->N2, 0, tw,
+                 q->tw16k, 0, L, 0};
+    PBHCHECK(launch_col<OP_FWD_TW>(q->N1, c1, st));
+    PBHCHECK(launch_rowfft(q->N2, q->chirp, q->tw16k, (int64_t)nplanes * q->N1, st));
+    if (q->P > 1) {   // rows into the split order (row_k1)
+        hipLaunchKernelGGL(k_row_permute, dim3(4096), dim3(256), 0, st, (const cf*)q->chirp, scratch, q->N1, q->N2, q->P, nplanes);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(q->chirp, scratch, sizeof(cf) * (size_t)L * nplanes, hipMemcpyDeviceToDevice, st));
+    }
+    return PBH_OK;
+}
+
 static int setup_bluestein(pbh_plan* p) {
     const int64_t N = p->N, L = p->bsL;
     #ifdef PBH_F64
@@ -873,17 +935,7 @@ static int setup_bluestein(pbh_plan* p) {
         SmallParams sp{p->bs_a, q->chirp, nullptr, q->tw16k, 1, 1, 0, L, -1, (real)1};
         PBHCHECK(launch_small((int)L, sp, st));
     } else {
-        BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
-        ColSide planar{LAYOUT_PLANAR, L, q->N2};
-        ColParams c1{q->chirp, q->chirp, planar, planar, LAYOUT_PLANAR, 0, 0, 1, q->N2, (int64_t)q->N2, 0, tw,
-                     q->tw16k, 0, L, 0};
-        PBHCHECK(launch_col<OP_FWD_TW>(q->N1, c1, st));
-        PBHCHECK(launch_rowfft(q->N2, q->chirp, q->tw16k, q->N1, st));
-        if (q->P > 1) {   // the sub-plan walks its rows in the split order (row_k1)
-            hipLaunchKernelGGL(k_row_permute, dim3(4096), dim3(256), 0, st, (const cf*)q->chirp, p->bs_a, q->N1, q->N2, q->P, 1);
-            HIPCHECK(hipGetLastError());
-            HIPCHECK(hipMemcpyAsync(q->chirp, p->bs_a, sizeof(cf) * (size_t)L, hipMemcpyDeviceToDevice, st));
-        }
+        PBHCHECK(spectrum_in_plan_order(q, 1, p->bs_a, st));
     }
     HIPCHECK(hipStreamSynchronize(st));
     q->has_chirp = true;
@@ -960,19 +1012,7 @@ static int rebuild_circular_filter(pbh_plan* p) {
                 if (rc == PBH_OK) rc = launch_small((int)L, sp, st);
             }
         } else {
-            BigTwiddle tw{q->tw_hi, q->tw_lo, q->tw_shift, L - 1};
-            ColSide planar{LAYOUT_PLANAR, L, q->N2};
-            ColParams c1{q->chirp, q->chirp, planar, planar, LAYOUT_PLANAR, 0, 0, nchan, q->N2, (int64_t)nchan * q->N2, 0,
-                         tw, q->tw16k, 0, L, 0};
-            rc = launch_col<OP_FWD_TW>(q->N1, c1, st);
-            if (rc == PBH_OK) rc = launch_rowfft(q->N2, q->chirp, q->tw16k, (int64_t)nchan * q->N1, st);
-            if (rc == PBH_OK && q->P > 1) {   // the convolution plan walks its rows in the split order (row_k1)
-                hipLaunchKernelGGL(k_row_permute, dim3(4096), dim3(256), 0, st, (const cf*)q->chirp, p->cf_in, q->N1, q->N2,
-                                   q->P, nchan);
-                if (hipGetLastError() != hipSuccess ||
-                    hipMemcpyAsync(q->chirp, p->cf_in, sizeof(cf) * (size_t)L * nchan, hipMemcpyDeviceToDevice, st) != hipSuccess)
-                    rc = fail(PBH_ERR_HIP, "row permutation of the filter spectrum failed");
-            }
+            rc = spectrum_in_plan_order(q, nchan, p->cf_in, st);
         }
     }
     hipStreamSynchronize(st);
@@ -1001,6 +1041,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     if (dtype != PBH_C64) return fail(PBH_ERR_INVALID, "dtype mismatch (float32 build)");
 #endif
     const bool pow2 = is_pow2(nsample) && nsample >= PBH_R && !plain_fft;
+    const int odd_m = plain_fft ? 0 : native_odd_factor(nsample);   // nsample = m * 2^k, m in {3, 5, 7}: native too
     if (nsample < 2 || nsample > (1LL << 28) || (!pow2 && nsample > (1LL << 27)))
         return fail(PBH_ERR_UNSUPPORTED, "nsample must be in [2, 2^28] (powers of two) or [2, 2^27] (other lengths); got " +
                                              std::to_string(nsample));
@@ -1022,12 +1063,15 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     p->start = crop_start;
     p->stop = crop_stop < crop_start ? crop_start : crop_stop;  // empty result if the crop is negative
     const int n = ilog2(nsample);
-    if (!pow2) {
-        p->N1 = 1;  // natural-order chirp H/N; the transforms run in the power-of-two sub-plan
+    if (odd_m) {
+        // the odd factor is the radix-P stage of the split column transform: N1 = m * Q rows, Q a power of two
+        p->N2 = kTilePoints;
+        p->N1 = (int)(nsample / kTilePoints);
+        p->P = odd_m;
+    } else if (!pow2) {
+        p->N1 = 1;  // natural-order chirp H/N; the transforms run in a native-length convolution plan
         p->N2 = (int)nsample;
-        int64_t L = PBH_R;
-        while (L < 2 * nsample - 1) L <<= 1;
-        p->bsL = L;
+        p->bsL = plain_fft ? next_pow2_at_least(2 * nsample - 1) : convolution_length(2 * nsample - 1);
     } else if (n <= kTileLog2) {
         p->N1 = 1;
         p->N2 = (int)nsample;
@@ -1036,7 +1080,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
     }
-    if (p->N1 > 1) {
+    if (p->N1 > 1 && !odd_m) {
         // column tiles whose rows are narrower than a 128-byte line are avoided by splitting N1 = P * Q with
         // Q rows per tile such that a tile row is one line; PBH_QMAX overrides Q (tests exercise the split at
         // small sizes)
@@ -1083,7 +1127,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     if (p->N1 > 1) {
         // W_N^p = hi[p >> shift] * lo[p & mask], float64
         p->tw_shift = (n + 1) / 2;
-        const int64_t nlo = 1LL << p->tw_shift, nhi = nsample >> p->tw_shift;
+        const int64_t nlo = 1LL << p->tw_shift, nhi = ((nsample - 1) >> p->tw_shift) + 1;
         std::vector<double2> lo(nlo), hi(nhi);
         for (int64_t i = 0; i < nlo; ++i) {
             double a = -2.0 * M_PI * (double)i / (double)nsample;

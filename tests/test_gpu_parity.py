@@ -647,3 +647,43 @@ def test_split_column_transform_nonpow2(small_qmax):
     assert series_errors(y, yr)[0] < RTOL_L2
     f = pb.fft.fft(z.to_device().data, axis=0)      # plain ring transform (its sub-plan is split too)
     assert np.linalg.norm(np.asarray(f) - np.fft.fft(x, axis=0)) / np.linalg.norm(np.fft.fft(x, axis=0)) < 2e-6
+
+
+# ---- lengths m * 2^k (m = 3, 5, 7) run natively: the odd factor is the radix-P stage of the split column pass ------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,shape_tail,dtype", [
+    (3 << 19, (2, 2), np.complex64), (5 << 19, (2, 2), np.complex64), (7 << 19, (1, 2), np.complex64),
+    (3 << 20, (3,), np.complex64),            # 3 series: stand-alone radix stage + two-axis layout tiles
+    (5 << 17, (2, 2), np.complex128), (3 << 18, (2,), np.complex128),
+])
+def test_odd_factor_lengths(n, shape_tail, dtype):
+    from pulsarbat_amd.transforms.dedispersion import _prepare, clear_plan_cache
+    clear_plan_cache()
+    rng = np.random.default_rng(31)
+    shape = (n,) + shape_tail
+    x = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 2 ** -0.5).astype(dtype)
+    z = make_signal(x, 1e6, 1e9, start_time=pb.Time(56000.0, format="mjd"))
+    dm = 30.0
+    yr, start, stop = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    tol = RTOL_L2 if dtype == np.complex64 else RTOL_F64
+    plan, _, _, _ = _prepare(z.to_device(), pb.DM(dm), None, None, "auto")
+    assert plan.info["nkernel"] in (5, 7)            # a native multi-pass plan, not the convolution detour
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(dm))
+    assert y.shape == yr.shape and series_errors(y, yr)[0] < tol
+    assert abs((y.start_time - z.start_time).to_value(u.s) - start / 1e6) < 1e-12
+    chirp = orc.chirp_from_signal(dm, x.shape, 1e6, 1e9)
+    y2 = pb.coherent_dedispersion(z.to_device(), pb.DM(dm), chirp=chirp)
+    assert series_errors(y2, yr)[0] < tol
+    got = pb.DM(dm).chirp_from_signal(z.to_device())
+    assert np.abs(np.asarray(got).reshape(chirp.shape) - chirp).max() < 2.5e-7
+
+
+@pytest.mark.gpu
+def test_arbitrary_length_uses_short_convolution():
+    """2N - 1 = 1 400 001 -> convolution length 3 * 2^19 = 1 572 864 instead of 2^21."""
+    rng = np.random.default_rng(32)
+    x = (rng.standard_normal((700001, 2, 2)) + 1j * rng.standard_normal((700001, 2, 2))).astype(np.complex64)
+    z = make_signal(x, 1e6, 1e9)
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(7.0))
+    yr, _, _ = orc.coherent_dedispersion(x, 7.0, 1e6, 1e9)
+    assert series_errors(y, yr)[0] < RTOL_L2
