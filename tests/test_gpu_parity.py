@@ -679,10 +679,11 @@ def test_odd_factor_lengths(n, shape_tail, dtype):
 
 
 @pytest.mark.gpu
-def test_arbitrary_length_uses_short_convolution():
-    """2N - 1 = 1 400 001 -> convolution length 3 * 2^19 = 1 572 864 instead of 2^21."""
+@pytest.mark.parametrize("n", [700001, 1200007, 1700003])
+def test_arbitrary_length_uses_short_convolution(n):
+    """2N - 1 = 1.4 M -> convolution length 3 * 2^19 (not 2^21); 2.4 M -> 5 * 2^19 (not 2^22); 3.4 M -> 7 * 2^19."""
     rng = np.random.default_rng(32)
-    x = (rng.standard_normal((700001, 2, 2)) + 1j * rng.standard_normal((700001, 2, 2))).astype(np.complex64)
+    x = (rng.standard_normal((n, 1, 2)) + 1j * rng.standard_normal((n, 1, 2))).astype(np.complex64)
     z = make_signal(x, 1e6, 1e9)
     y = pb.coherent_dedispersion(z.to_device(), pb.DM(7.0))
     yr, _, _ = orc.coherent_dedispersion(x, 7.0, 1e6, 1e9)
