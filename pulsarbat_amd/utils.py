@@ -8,7 +8,7 @@ import numpy as np
 from . import _hip
 from .device import DeviceArray
 
-__all__ = ["real_to_complex", "next_fast_len", "prev_fast_len"]
+__all__ = ["real_to_complex", "next_fast_len", "prev_fast_len", "next_native_len", "prev_native_len"]
 
 
 def real_to_complex(z, axis=0):
@@ -80,3 +80,38 @@ def prev_fast_len(target):
     if target < 1:
         raise ValueError("target must be a positive integer")
     return _smooth_7(target)[-1]
+
+
+def _native_lens(limit):
+    """Lengths the HIP pipeline transforms without a convolution detour ("Lengths"): powers of two
+    from 32, and m * 2^k with m in (3, 5, 7) and 2^19 <= 2^k <= 2^24 (complex64 tile sizes), ascending, <= limit."""
+    vals = set()
+    v = 32
+    while v <= limit and v <= 1 << 28:
+        vals.add(v)
+        v *= 2
+    for m in (3, 5, 7):
+        for k in range(19, 25):
+            if m << k <= limit:
+                vals.add(m << k)
+    return sorted(vals)
+
+
+def next_native_len(target):
+    """Smallest length >= target that runs natively on the device (the analogue of ``next_fast_len`` for this
+    build: 7-smooth lengths in general go through one padded convolution, about 2x the native cost)."""
+    target = int(target)
+    if target < 1:
+        raise ValueError("target must be a positive integer")
+    limit = 32
+    while limit < target:
+        limit *= 2
+    return next(v for v in _native_lens(limit) if v >= target)
+
+
+def prev_native_len(target):
+    """Largest natively transformed length <= target (at least 32)."""
+    target = int(target)
+    if target < 32:
+        raise ValueError("target must be at least 32")
+    return _native_lens(target)[-1]

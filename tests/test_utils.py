@@ -23,6 +23,16 @@ def test_fast_len():
     assert len(pb.fast_len(z)) == 1000
 
 
+def test_native_len():
+    from pulsarbat_amd.utils import next_native_len, prev_native_len
+    assert next_native_len(1) == 32 and next_native_len(33) == 64 and prev_native_len(100) == 64
+    assert next_native_len(10_000_000) == 5 << 21 and prev_native_len(10_000_000) == 1 << 23
+    assert next_native_len((3 << 20) - 5) == 3 << 20 and prev_native_len(3 << 20) == 3 << 20
+    assert prev_native_len(7 << 24) == 7 << 24 and next_native_len((7 << 24) + 1) == 1 << 27
+    with pytest.raises(ValueError):
+        prev_native_len(8)
+
+
 def gen_input(t, w, p):
     return np.cos(w * t + p)
 
