@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-series", action="store_true", help="skip the series-major secondary figure")
+    ap.add_argument("--gather", action="store_true", help="(multi-rank) also time the all-gather of the outputs")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--log2n", type=int, default=24, help="(debug) nsample = 2^log2n")
     ap.add_argument("--dm", type=float, default=DM, help="(debug) dispersion measure")
@@ -190,6 +191,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # optional: the one real exchange step of the sharded path, an all-gather of the outputs along the channel
+    # axis (results are left sharded by default; the gather is timed separately)
+    gather_ms = None
+    if distributed and args.gather:
+        try:
+            sig = pb.DualPolarizationSignal(y, sample_rate=sr * u.Hz, center_freq=float(np.mean(freqs)) * u.Hz,
+                                            pol_type="linear")
+            from pulsarbat_amd.shard import _all_gather_channels
+            lo, hi = (CENTER_HZ - BAND_HZ / 2) * u.Hz, (CENTER_HZ + BAND_HZ / 2) * u.Hz
+            _all_gather_channels(sig, lo, hi, None)
+            barrier()
+            t1 = time.perf_counter()
+            full = _all_gather_channels(sig, lo, hi, None)
+            barrier()
+            gather_ms = (time.perf_counter() - t1) * 1e3
+            del full
+        except Exception as exc:   # never lose the main line to the optional figure
+            gather_ms = repr(exc)
+
     # secondary figure: the same block kept series-major (time fastest) in HBM at both ends, as a
     # device-resident pipeline would keep it -- the two layout passes disappear (3 kernels)
     series_major = None
@@ -258,6 +278,8 @@ def main():
         }
         if series_major is not None:
             result["series_major_io"] = series_major
+        if gather_ms is not None:
+            result["all_gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu:
             try:
                 result["cpu_baseline"] = cpu_baseline()
