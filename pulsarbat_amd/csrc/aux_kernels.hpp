@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void k_chirp_reorder(const float2* __restrict_
 // through an LDS tile padded to S+1 per row so the transposed read is conflict-free.
 constexpr int kTrElems = 4096;
 
+// nvalid <= N: time samples at and beyond nvalid are not read but taken as zero (the zero padding of the
+// convolution plan of an arbitrary-length transform happens here instead of in a copy + memset pass)
 __global__ __launch_bounds__(256) void k_deinterleave(const cf* __restrict__ in, cf* __restrict__ out,
-                                                      int64_t N, int S, int TN, int64_t plane) {
+                                                      int64_t N, int S, int TN, int64_t plane, int64_t nvalid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     const int64_t n0 = (int64_t)blockIdx.x * TN;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_deinterleave(const cf* __restrict__ in,
     const int cnt = rows * S;
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
         int n = e / S, s = e - n * S;
-        lds[n * (S + 1) + s] = in[n0 * S + e];
+        lds[n * (S + 1) + s] = (n0 + n < nvalid) ? in[n0 * S + e] : make_cf(0, 0);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
 // time samples (32 KiB) through LDS, reading and writing 512-byte runs on both sides.  Any S (f32: even), any N.
 template <int SB, int TB>
 __global__ __launch_bounds__(256) void k_deint_blk(const cf* __restrict__ in, cf* __restrict__ out, int64_t N, int S,
-                                                   int64_t plane) {
+                                                   int64_t plane, int64_t nvalid) {
     constexpr int VE = 16 / (int)sizeof(cf);          // elements per 16-byte vector (2 for complex64, 1 for complex128)
     constexpr int LD = TB + 1;
     constexpr int NV = SB * TB / VE / 256;
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256) void k_deint_blk(const cf* __restrict__ in, cf
         const int s = s0 + sv * VE;
         if (n0 + t < N && s < S) {
             union { vec16 v; cf c[VE]; } x;
-            x.v = *reinterpret_cast<const vec16*>(in + (n0 + t) * S + s);
+            if (n0 + t < nvalid) x.v = *reinterpret_cast<const vec16*>(in + (n0 + t) * S + s);
+            else x.v = vec16{0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < VE; ++e) lds[(sv * VE + e) * LD + t] = x.c[e];
         }
@@ -205,14 +208,22 @@ __global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf
 // streaming-copy calibration (tools/micro/membench.hip) found fastest on MI355X.
 template <int S>
 __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
-                                                         int64_t N, int64_t plane) {
+                                                         int64_t N, int64_t plane, int64_t nvalid) {
     constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;  // 8 float4 per thread
     __shared__ cf lds[S * LD];
     const int64_t n0 = (int64_t)blockIdx.x * TN;
     const float4* src = reinterpret_cast<const float4*>(in + n0 * S);
     float4 v[NV];
+    if (n0 + TN <= nvalid) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = src[threadIdx.x + 256 * j];
+        for (int j = 0; j < NV; ++j) v[j] = src[threadIdx.x + 256 * j];
+    } else {   // tile at or beyond the end of the data: zero padding
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 2 * (threadIdx.x + 256 * j);
+            v[j] = (n0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : make_float4(0, 0, 0, 0);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int e = 2 * (threadIdx.x + 256 * j);
@@ -301,7 +312,7 @@ __device__ __forceinline__ void radix_twiddles(cf (&tw)[P], int64_t b, int N1, i
 
 template <int S, int P>
 __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, cf* __restrict__ out, int64_t chunk,
-                                                     int64_t plane, int N2, int N1) {
+                                                     int64_t plane, int N2, int N1, int64_t nvalid) {
     constexpr int E = RadixTile<P>::E, TN = E / S, LD = TN + 1, NV = E / 2 / 256;
     __shared__ cf lds[S * LD];
     const int64_t n0 = (int64_t)blockIdx.x * TN;
@@ -309,8 +320,12 @@ __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, 
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         const float4* src = reinterpret_cast<const float4*>(in + ((int64_t)a * chunk + n0) * S);
+        const int64_t t0 = (int64_t)a * chunk + n0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[a][j] = src[threadIdx.x + 256 * j];
+        for (int j = 0; j < NV; ++j) {
+            const int e = 2 * (threadIdx.x + 256 * j);
+            v[a][j] = (t0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : make_float4(0, 0, 0, 0);   // zero padding
+        }
     }
     cf tw[P];
     radix_twiddles<P>(tw, n0 / N2, N1, -1);

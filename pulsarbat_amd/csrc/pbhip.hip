@@ -391,10 +391,10 @@ static int blk_series(int S, int64_t N) {
     return sb;
 }
 template <int SB>
-static int launch_deint_blk(const cf* in, cf* work, int64_t N, int S, int64_t plane, hipStream_t st) {
+static int launch_deint_blk(const cf* in, cf* work, int64_t N, int S, int64_t plane, int64_t nvalid, hipStream_t st) {
     constexpr int TB = kBlkElems / SB;
     hipLaunchKernelGGL((k_deint_blk<SB, TB>), dim3((unsigned)((N + TB - 1) / TB), (unsigned)((S + SB - 1) / SB)), dim3(256), 0, st,
-                       in, work, N, S, plane);
+                       in, work, N, S, plane, nvalid);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -407,20 +407,21 @@ static int launch_reint_blk(const cf* work, cf* out, int64_t start, int64_t stop
     return PBH_OK;
 }
 
-static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStream_t st) {
+// nvalid: input time samples that exist (the rest of the N is zero padding; N for an ordinary call)
+static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t nvalid, hipStream_t st) {
     switch (blk_series(S, N)) {
-        case 4: return launch_deint_blk<4>(in, work, N, S, N, st);
-        case 8: return launch_deint_blk<8>(in, work, N, S, N, st);
-        case 16: return launch_deint_blk<16>(in, work, N, S, N, st);
-        case 32: return launch_deint_blk<32>(in, work, N, S, N, st);
-        case 64: return launch_deint_blk<64>(in, work, N, S, N, st);
+        case 4: return launch_deint_blk<4>(in, work, N, S, N, nvalid, st);
+        case 8: return launch_deint_blk<8>(in, work, N, S, N, nvalid, st);
+        case 16: return launch_deint_blk<16>(in, work, N, S, N, nvalid, st);
+        case 32: return launch_deint_blk<32>(in, work, N, S, N, nvalid, st);
+        case 64: return launch_deint_blk<64>(in, work, N, S, N, nvalid, st);
     }
     const int TN = tr_rows(S);
 #ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
-#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, N); break;
+#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, N, nvalid); break;
             X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
         }
@@ -429,7 +430,7 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, hipStre
     }
 #endif
     hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
-                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N);
+                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N, nvalid);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -484,10 +485,10 @@ static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
 }
 #ifndef PBH_F64
 template <int S>
-static int launch_deint_radix_s(int P, const cf* in, cf* work, int64_t N, int N2, int N1, hipStream_t st) {
+static int launch_deint_radix_s(int P, const cf* in, cf* work, int64_t N, int N2, int N1, int64_t nvalid, hipStream_t st) {
     const int64_t chunk = N / P;
     switch (P) {
-#define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1); break;
+#define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1, nvalid); break;
         X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
     }
@@ -507,10 +508,11 @@ static int launch_reint_radix_s(int P, const cf* work, cf* out, int64_t N, int N
     return PBH_OK;
 }
 #endif
-static int launch_deint_radix(int S, int P, const cf* in, cf* work, int64_t N, int N2, int N1, hipStream_t st) {
+static int launch_deint_radix(int S, int P, const cf* in, cf* work, int64_t N, int N2, int N1, int64_t nvalid,
+                              hipStream_t st) {
 #ifndef PBH_F64
     switch (S) {
-#define X(s) case s: return launch_deint_radix_s<s>(P, in, work, N, N2, N1, st);
+#define X(s) case s: return launch_deint_radix_s<s>(P, in, work, N, N2, N1, nvalid, st);
         X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
     }
@@ -543,6 +545,7 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 struct IoLayout {
     int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
     int64_t in_pitch = 0, out_pitch = 0;
+    int64_t in_valid = -1;   // sample-major input: time samples present (the rest of nsample is zero padding); -1 = all
 };
 
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
@@ -551,13 +554,20 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     const int S = p->S;
     if (p->bsL && p->cfilt) {
         const int64_t N = p->N, L = p->bsL;
-        cf* pad = p->cf_in;
+        pbh_plan* q = p->cfilt;
+        if (q->N1 > 1 && resolved_variant(q) == PBH_VARIANT_PLANAR5) {
+            // the convolution plan's de-interleave pass reads the N samples that exist and zero-fills the rest
+            IoLayout pad_io;
+            pad_io.in_valid = N;
+            return build_steps(q, in, out, DetectTail(), pad_io);
+        }
+        cf* pad = p->cf_in;   // 3-pass and single-tile plans read their input directly: pad it first
         steps.push_back({"k_pad", [=](hipStream_t st) {
             HIPCHECK(hipMemcpyAsync(pad, in, sizeof(cf) * (size_t)N * S, hipMemcpyDeviceToDevice, st));
             HIPCHECK(hipMemsetAsync(pad + N * S, 0, sizeof(cf) * (size_t)(L - N) * S, st));
             return (int)PBH_OK;
         }});
-        for (auto& s2 : build_steps(p->cfilt, pad, out)) steps.push_back(s2);
+        for (auto& s2 : build_steps(q, pad, out)) steps.push_back(s2);
         return steps;
     }
     if (p->bsL) {
@@ -604,7 +614,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 
     // one series: the (nsample, 1) block is its own series-major form -- no layout passes are needed at all
     // (matters for long blocks, where the 3-pass variant is not available)
-    if (S == 1 && p->P > 1 && !tail.out && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR && io.out_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
+    if (S == 1 && p->P > 1 && !tail.out && io.in_valid < 0 && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR &&
+        io.out_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
         io.in_layout = io.out_layout = PBH_LAYOUT_SERIES_MAJOR;
         io.in_pitch = p->N;
         io.out_pitch = p->stop - p->start;
@@ -613,14 +624,15 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     if (variant == PBH_VARIANT_PLANAR5 || in_sm || out_sm) {
         const int64_t N = p->N, start = p->start, stop = p->stop;
         const bool fuse_radix = p->P > 1 && !in_sm && !out_sm && radix_layout_ok(S, p->P, N, N2);
+        const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
         if (fuse_radix) {
             const int Pf = p->P;
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
-                return launch_deint_radix(S, Pf, in, work, N, N2, N1, st);
+                return launch_deint_radix(S, Pf, in, work, N, N2, N1, nvalid, st);
             }});
         } else if (!in_sm)
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
-                return launch_deinterleave(in, work, N, S, st);
+                return launch_deinterleave(in, work, N, S, nvalid, st);
             }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         const int P = p->P, Q = N1 / P;
@@ -1200,7 +1212,8 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     if (p->bsL && p->cfilt) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->cfilt, &sub);
-        info->nkernel = 1 + sub.nkernel;
+        // + the padding copy, unless the convolution plan's own de-interleave pass does the zero padding
+        info->nkernel = sub.nkernel + ((p->cfilt->N1 > 1 && sub.variant == PBH_VARIANT_PLANAR5) ? 0 : 1);
     } else if (p->bsL) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->sub, &sub);
