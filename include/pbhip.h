@@ -188,7 +188,8 @@ int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* ou
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);
 
 /* Backs pb.fft.fft / pb.fft.ifft for device arrays (pulsarbat/fft.py:30-48 -> scipy.fft.fft/ifft,
- * norm=None): c2c along axis 0 of a C-contiguous (n, batch) c64 array.                              */
+ * norm=None): c2c along axis 0 of a C-contiguous (n, batch) array.  n up to one tile: one kernel; 2^k and
+ * m * 2^k (m = 3, 5, 7) beyond it: multi-pass transform + natural-order output pass; other n: Bluestein.  */
 int pbh_fft_c2c(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t n,
                 int64_t batch, int inverse, int in_loc, int out_loc);
 

@@ -202,6 +202,76 @@ __global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf
     }
 }
 
+// ---- last pass of a stand-alone multi-pass FFT (pbh_fft_c2c beyond one tile) --------------------------------
+// After the column pass and the row transforms the spectrum sits in plan order: series s, row r (holding
+// k1 = row_k1(r)), position k2 -> bin k = k1 + N1*k2.  This pass writes it in natural order, (n, B)
+// interleaved: out[k*B + s].  Seen as a transpose it is k_reint_blk with "series" j = k1*B + s (N1*B of
+// them) and "time" k2, so both sides move 512-byte runs.  inverse: out[((N - k) % N)*B + s] = value * scale,
+// which turns the forward transform into the unnormalised-inverse-times-scale (ifft with scale = 1/N).
+// 16-byte stores when B is a multiple of the elements per 16 bytes, 8-byte stores otherwise.
+template <int SB, int TB>
+__global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* __restrict__ out, int N1, int N2, int B,
+                                                 int P, int inverse, real scale) {
+    constexpr int VE = 16 / (int)sizeof(cf);
+    constexpr int LD = TB + 1;
+    constexpr int NE = SB * TB / 256, NV = SB * TB / VE / 256;
+    typedef float vec16 __attribute__((ext_vector_type(4)));
+    __shared__ cf lds[SB * LD];
+    const int64_t k20 = (int64_t)blockIdx.y * TB;
+    const int64_t j0 = (int64_t)blockIdx.x * SB, ncol = (int64_t)N1 * B;
+    const int Q = N1 / P;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int sl = q / TB, t = q % TB;
+        const int64_t col = j0 + sl;
+        if (col < ncol && k20 + t < N2) {
+            const int64_t k1 = col / B;
+            const int s = (int)(col - k1 * B);
+            const int64_t r = P > 1 ? (k1 % P) * Q + k1 / P : k1;
+            lds[sl * LD + t] = in[((int64_t)s * N1 + r) * N2 + k20 + t];
+        }
+    }
+    __syncthreads();
+    const int64_t N = (int64_t)N1 * N2;
+    if (VE > 1 && B % VE != 0) {   // odd number of complex64 series: 8-byte stores, still contiguous across the lanes
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int q = threadIdx.x + 256 * j;
+            const int t = q / SB, sl = q % SB;
+            const int64_t col = j0 + sl;
+            if (k20 + t < N2 && col < ncol) {
+                const cf a = lds[sl * LD + t];
+                const int64_t k1 = col / B;
+                const int s = (int)(col - k1 * B);
+                int64_t k = k1 + (int64_t)N1 * (k20 + t);
+                if (inverse) k = k ? N - k : 0;
+                out[k * B + s] = make_cf(a.x * scale, a.y * scale);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int t = q / (SB / VE), sv = q % (SB / VE);
+        const int64_t col = j0 + (int64_t)sv * VE;
+        if (k20 + t < N2 && col < ncol) {
+            union { vec16 v; cf c[VE]; } x;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const cf a = lds[(sv * VE + e) * LD + t];
+                x.c[e] = make_cf(a.x * scale, a.y * scale);
+            }
+            const int64_t k1 = col / B;
+            const int s = (int)(col - k1 * B);
+            int64_t k = k1 + (int64_t)N1 * (k20 + t);
+            if (inverse) k = k ? N - k : 0;
+            *reinterpret_cast<vec16*>(out + k * B + s) = x.v;   // B % VE == 0: the VE elements share one k
+        }
+    }
+}
+
 #ifndef PBH_F64
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the

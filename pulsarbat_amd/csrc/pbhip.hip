@@ -971,7 +971,7 @@ const char* pbh_last_error(void) { return g_err.c_str(); }
 const char* pbh_version(void) { return "pbhip 0.1.0 (gfx950)"; }
 
 static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
-                       int64_t crop_start, int64_t crop_stop, bool plain_fft);
+                       int64_t crop_start, int64_t crop_stop, int plain_fft /* 0 dedispersion plan, 1 Bluestein ring, 2 native transform only */);
 
 // Non-power-of-two dedispersion plans: the (bsL, nchan, npol) convolution plan and its padded input.
 static int fft_c2c_ring(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse);
@@ -983,7 +983,7 @@ static int setup_circular(pbh_plan* p) {
 #else
     const int dt = PBH_C64;
 #endif
-    PBHCHECK(create_plan(&p->cfilt, p->device, L, p->nchan, p->npol, dt, (N - 1) + p->start, (N - 1) + p->stop, false));
+    PBHCHECK(create_plan(&p->cfilt, p->device, L, p->nchan, p->npol, dt, (N - 1) + p->start, (N - 1) + p->stop, 0));
     p->cfilt->perm_w = 0;
     p->owned_bytes += p->cfilt->owned_bytes;
     PBHCHECK(dev_alloc(p, (void**)&p->cf_in, sizeof(cf) * (size_t)L * p->S));
@@ -1039,11 +1039,11 @@ static int rebuild_circular_filter(pbh_plan* p) {
 
 int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
                     int64_t crop_start, int64_t crop_stop) {
-    return create_plan(out, device, nsample, nchan, npol, dtype, crop_start, crop_stop, false);
+    return create_plan(out, device, nsample, nchan, npol, dtype, crop_start, crop_stop, 0);
 }
 
 static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, int npol, int dtype,
-                       int64_t crop_start, int64_t crop_stop, bool plain_fft) {
+                       int64_t crop_start, int64_t crop_stop, int plain_fft) {
     if (!out) return fail(PBH_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (nsample <= 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "non-positive dimension");
@@ -1052,8 +1052,8 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
 #else
     if (dtype != PBH_C64) return fail(PBH_ERR_INVALID, "dtype mismatch (float32 build)");
 #endif
-    const bool pow2 = is_pow2(nsample) && nsample >= PBH_R && !plain_fft;
-    const int odd_m = plain_fft ? 0 : native_odd_factor(nsample);   // nsample = m * 2^k, m in {3, 5, 7}: native too
+    const bool pow2 = is_pow2(nsample) && nsample >= PBH_R && plain_fft != 1;
+    const int odd_m = plain_fft == 1 ? 0 : native_odd_factor(nsample);   // nsample = m * 2^k, m in {3, 5, 7}: native too
     if (nsample < 2 || nsample > (1LL << 28) || (!pow2 && nsample > (1LL << 27)))
         return fail(PBH_ERR_UNSUPPORTED, "nsample must be in [2, 2^28] (powers of two) or [2, 2^27] (other lengths); got " +
                                              std::to_string(nsample));
@@ -1067,7 +1067,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
 
     pbh_plan* p = new pbh_plan();
     p->device = device;
-    p->plain_fft = plain_fft;
+    p->plain_fft = plain_fft != 0;
     p->N = nsample;
     p->nchan = nchan;
     p->npol = npol;
@@ -1084,6 +1084,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N1 = 1;  // natural-order chirp H/N; the transforms run in a native-length convolution plan
         p->N2 = (int)nsample;
         p->bsL = plain_fft ? next_pow2_at_least(2 * nsample - 1) : convolution_length(2 * nsample - 1);
+        if (plain_fft == 2) { delete p; return fail(PBH_ERR_UNSUPPORTED, "not a native length"); }
     } else if (n <= kTileLog2) {
         p->N1 = 1;
         p->N2 = (int)nsample;
@@ -1678,12 +1679,86 @@ static int ring_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
     const int dt = PBH_C64;
 #endif
     pbh_plan* p = nullptr;
-    PBHCHECK(create_plan(&p, device, n, 1, (int)batch, dt, 0, n, true));
+    PBHCHECK(create_plan(&p, device, n, 1, (int)batch, dt, 0, n, 1));
     Entry& e = cache[next];
     next ^= 1;
     if (e.plan) pbh_plan_destroy(e.plan);
     e = Entry{device, n, batch, p};
     *out = p;
+    return PBH_OK;
+}
+
+// Stand-alone transform of a native length (2^k beyond one tile, or m * 2^k) without the Bluestein detour:
+// de-interleave (+ radix stage), column pass, row transforms, natural-order output (k_fft_out).  Plans
+// (workspace and twiddles only) are cached per thread like the ring plans.
+static int native_fft_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
+    struct Entry { int device; int64_t n, batch; pbh_plan* plan; };
+    static thread_local Entry cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+    static thread_local int next = 0;
+    for (auto& e : cache)
+        if (e.plan && e.device == device && e.n == n && e.batch == batch) {
+            *out = e.plan;
+            return PBH_OK;
+        }
+#ifdef PBH_F64
+    const int dt = PBH_C128;
+#else
+    const int dt = PBH_C64;
+#endif
+    pbh_plan* p = nullptr;
+    PBHCHECK(create_plan(&p, device, n, (int)batch, 1, dt, 0, n, 2));
+    Entry& e = cache[next];
+    next ^= 1;
+    if (e.plan) pbh_plan_destroy(e.plan);
+    e = Entry{device, n, batch, p};
+    *out = p;
+    return PBH_OK;
+}
+
+static bool native_fft_ok(int64_t n, int64_t batch) {
+    static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
+    if (!on || batch > 65535 || n <= kTilePoints || n > (1LL << 28)) return false;
+    return (is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0;
+}
+
+static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
+    pbh_plan* p = nullptr;
+    PBHCHECK(native_fft_plan(device, n, batch, &p));
+    const int S = p->S, N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
+    cf* work = p->work;
+    BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, n - 1};
+    tw.nmod = is_pow2(n) ? 0 : n;
+    const bool fuse = P > 1 && S > 1 && radix_layout_ok(S, P, n, N2);
+    const cf* src = work;   // what the column pass reads
+    if (fuse) {
+        PBHCHECK(launch_deint_radix(S, P, din, work, n, N2, N1, n, st));
+    } else {
+        if (S > 1) PBHCHECK(launch_deinterleave(din, work, n, S, n, st));   // (one series is its own planar form)
+        if (P > 1) PBHCHECK(launch_radix<-1>(P, S > 1 ? work : din, n, work, n, S, n, N2, N1, 0, n, st));
+        else if (S == 1) src = din;
+    }
+    const bool colq = P > 1 || (Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && n < (1LL << 31));
+    if (colq) {
+        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+        HIPCHECK(hipMemsetAsync(ctr, 0, 3 * sizeof(unsigned), st));
+        ColpParams cp{work, n, S, N2, tw, p->tw16k, 0, n, 0, ctr};
+        cp.P = P;
+        if (src != work) {
+            cp.ld = src;
+            cp.ld_plane = n;
+        }
+        PBHCHECK(launch_colq<OP_FWD_TW>(Q, cp, st));
+    } else {
+        ColSide planar{LAYOUT_PLANAR, n, N2};
+        ColParams c1{src, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, (int64_t)S * N2, 0, tw, p->tw16k, 0, n, 0};
+        PBHCHECK(launch_col<OP_FWD_TW>(N1, c1, st));
+    }
+    PBHCHECK(launch_rowfft(N2, work, p->tw16k, (int64_t)S * N1, st));
+    constexpr int SB = 64, TB = kBlkElems / 64;
+    const int64_t ncol = (int64_t)N1 * S;
+    hipLaunchKernelGGL((k_fft_out<SB, TB>), dim3((unsigned)((ncol + SB - 1) / SB), (unsigned)((N2 + TB - 1) / TB)), dim3(256), 0, st,
+                       (const cf*)work, dout, N1, N2, S, P, inverse, inverse ? (real)(1.0 / (double)n) : (real)1);
+    HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
 
@@ -1747,6 +1822,8 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     if (one_tile) {
         SmallParams sp{din, dout, nullptr, tw, (int)batch, 1, 0, n, inverse ? +1 : -1, (real)(1.0 / (double)n)};
         rc = launch_small((int)n, sp, st);
+    } else if (native_fft_ok(n, batch)) {
+        rc = fft_c2c_native(device, st, din, dout, n, batch, inverse);
     } else {
         rc = fft_c2c_ring(device, st, din, dout, n, batch, inverse);
     }

@@ -688,3 +688,46 @@ def test_arbitrary_length_uses_short_convolution(n):
     y = pb.coherent_dedispersion(z.to_device(), pb.DM(7.0))
     yr, _, _ = orc.coherent_dedispersion(x, 7.0, 1e6, 1e9)
     assert series_errors(y, yr)[0] < RTOL_L2
+
+
+# ---- pb.fft.fft / ifft of native lengths beyond one tile: multi-pass transform + natural-order output pass ---------
+def _fft_check(x, tol):
+    import scipy.fft
+    d = pb.DeviceArray.from_host(x)
+    for name in ("fft", "ifft"):
+        got = np.asarray(getattr(pb.fft, name)(d, axis=0))
+        want = getattr(scipy.fft, name)(x.astype(np.complex128), axis=0)
+        assert got.dtype == x.dtype and got.shape == x.shape
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < tol
+    # a delta at n0 -> exp(-2 pi i k n0 / N): catches any bin permutation exactly
+    n0 = x.shape[0] // 3 + 1
+    e = np.zeros_like(x)
+    e[n0] = 1
+    got = np.asarray(pb.fft.fft(pb.DeviceArray.from_host(e), axis=0))
+    k = np.arange(x.shape[0])
+    want = np.exp(-2j * np.pi * ((k * n0) % x.shape[0]) / x.shape[0])
+    assert np.abs(got - want.reshape((-1,) + (1,) * (x.ndim - 1))).max() < (1e-5 if x.dtype == np.complex64 else 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,tail,dtype", [
+    (1 << 15, (2,), np.complex64), (1 << 19, (2, 2), np.complex64), (1 << 22, (4,), np.complex64),
+    (3 << 19, (2,), np.complex64), (5 << 19, (2, 2), np.complex64), (7 << 20, (2,), np.complex64),
+    (1 << 20, (3, 2), np.complex64),          # 6 series: two-axis layout tiles in front
+    (1 << 19, (3,), np.complex64), (1 << 17, (1,), np.complex64),   # odd batch: 8-byte stores in the output pass
+    (1 << 14, (3,), np.complex128), (1 << 18, (2, 2), np.complex128), (3 << 18, (1,), np.complex128),
+])
+def test_fft_native_lengths(n, tail, dtype):
+    rng = np.random.default_rng(n % 1000 + len(tail))
+    x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(dtype)
+    _fft_check(x, 2e-6 if dtype == np.complex64 else 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,tail", [(1 << 20, (2,)), (1 << 22, (8,)), (1 << 21, (6,)), (1 << 22, (1,)), (1 << 21, (3,))])
+def test_fft_native_split_column(n, tail, small_qmax):
+    """Same with the split column transform (P = 2 .. 8 at these sizes with PBH_QMAX=32): rows permuted."""
+    small_qmax.setenv("PBH_QMAX", "32")
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(np.complex64)
+    _fft_check(x, 2e-6)
