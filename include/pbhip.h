@@ -183,6 +183,36 @@ int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int
 int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsample, void* host_out,
                           int64_t* nchunk, float* ms_total);
 
+/* ---- reader-side decode ----------------------------------------------------------------------- */
+/* Replaces the host post-processing of the reference's baseband readers
+ * (pulsarbat/readers/_baseband_readers.py:136-153 `_read_baseband`: per-series sideband conjugation and
+ * `astype(complex64)`; :223-226 GUPPIRawReader / :268-275 DADAStokesReader `_read_array`: axis transposes and
+ * channel flip) together with the integer -> float unpacking that precedes it, so that the raw payload bytes
+ * are what crosses PCIe.  The byte range `raw` (host or device, `raw_bytes` long) is a sequence of blocks
+ * `blk_stride` bytes apart, each `hdr_bytes` of header followed by a payload holding `blk_samples` time
+ * samples; inside a payload, element (t, chan, pol) is element number
+ * elem0 + t*stride_t + chan*stride_c + pol*stride_p (strides in elements, may be negative), an element being
+ * `ncomp` components (1 real, 2 complex: re, im) of `nbits` bits each, low bits first within a byte.
+ *   nbits 8, code 0: two's complement (DADA, GUPPI);  code 1: offset binary, v - 128 (VDIF)
+ *   nbits 2: 4-level code 0..3 -> -3.3359, -1, +1, +3.3359 (VDIF / Mark 5)
+ * Output (device): float32 (ncomp 1) or complex64 (ncomp 2) array of logical shape (nsample, nchan, npol) in
+ * `out_layout` (pbh_layout; out_pitch in elements for PBH_LAYOUT_SERIES_MAJOR), values times `scale`, imaginary
+ * part negated for the series whose entry in conj_mask (host, nchan*npol bytes, may be NULL) is non-zero.
+ * `first` is the index of the first wanted sample counted from the first sample of the first block in `raw`. */
+typedef struct {
+    int nbits;
+    int ncomp;
+    int code;
+    int64_t blk_samples;
+    int64_t blk_stride;
+    int64_t hdr_bytes;
+    int64_t elem0;
+    int64_t stride_t, stride_c, stride_p;
+} pbh_raw_layout_t;
+int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc,
+               const pbh_raw_layout_t* layout, int64_t first, int64_t nsample, int nchan, int npol,
+               const unsigned char* conj_mask, float scale, void* out_dev, int out_layout, int64_t out_pitch);
+
 /* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
 int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nsample,
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);

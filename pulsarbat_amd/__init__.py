@@ -19,7 +19,8 @@ from .transforms import *
 from . import fft
 from . import contrib
 from . import utils
+from . import readers
 
-__all__ = ["fft", "contrib", "utils", "units", "Time", "DeviceArray", "InvalidSignalError"]
+__all__ = ["fft", "contrib", "utils", "readers", "units", "Time", "DeviceArray", "InvalidSignalError"]
 __all__.extend(core.__all__)
 __all__.extend(transforms.__all__)

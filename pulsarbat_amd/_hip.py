@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "fft_c2c",
+__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "fft_c2c",
            "chirp_function", "copy_bench"]
 
 HOST, DEVICE = 0, 1
@@ -48,6 +48,12 @@ class _PlanInfo(C.Structure):
                 ("alg_bytes_per_sample", C.c_double)]
 
 
+class _RawLayout(C.Structure):
+    _fields_ = [("nbits", C.c_int), ("ncomp", C.c_int), ("code", C.c_int), ("blk_samples", C.c_int64),
+                ("blk_stride", C.c_int64), ("hdr_bytes", C.c_int64), ("elem0", C.c_int64),
+                ("stride_t", C.c_int64), ("stride_c", C.c_int64), ("stride_p", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/pbhip.h declares
 SIGNATURES = {
     "pbh_device_count": (C.c_int, []),
@@ -73,6 +79,8 @@ SIGNATURES = {
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "pbh_decode": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_RawLayout), C.c_int64,
+                             C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_detect_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -385,6 +393,39 @@ def detect(x, mode="intensity", nscrunch=1):
     pin, lin = _ptr_loc(x)
     pout, lout = _ptr_loc(out)
     _check(lib().pbh_detect(dev, stream, code, pin, pout, int(n), int(nchan), npol, m, int(nscrunch), lin, lout))
+    return out
+
+
+def decode(raw, layout, first, nsample, nchan, npol, *, conj=None, scale=1.0, series_major=False, device=None):
+    """Raw integer payload bytes -> DeviceArray (nsample, nchan, npol) float32 / complex64 (pbh_decode).
+
+    ``raw``: C-contiguous uint8 numpy array (the bytes of whole blocks, headers included) or a uint8
+    DeviceArray; ``layout``: dict with the fields of ``pbh_raw_layout_t``; ``conj``: per-series booleans."""
+    from .device import DeviceArray
+    _require_device()
+    lay = _RawLayout(**{k: int(v) for k, v in layout.items()})
+    dtype = np.complex64 if lay.ncomp == 2 else np.float32
+    shape = (int(nsample), int(nchan), int(npol))
+    if isinstance(raw, DeviceArray):
+        dev = raw.device_index
+        praw, loc, nbytes = C.c_void_p(raw.data_ptr()), DEVICE, int(np.prod(raw.shape))
+    else:
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        import torch
+        dev = torch.cuda.current_device() if device is None else int(device)
+        praw, loc, nbytes = C.c_void_p(raw.ctypes.data), HOST, raw.size
+    if series_major and nchan * npol > 1:
+        out = DeviceArray.empty_series_major(shape, dtype, device=dev)
+        code, pitch = 1, out.series_major_pitch()
+    else:
+        out = DeviceArray.empty(shape, dtype, device=dev)
+        code, pitch = 0, 0
+    mask = None
+    if conj is not None:
+        mask = np.ascontiguousarray(np.broadcast_to(np.asarray(conj, dtype=bool), (nchan, npol)), dtype=np.uint8)
+    _check(lib().pbh_decode(dev, _stream_ptr(dev), praw, nbytes, loc, C.byref(lay), int(first), int(nsample), int(nchan),
+                            int(npol), None if mask is None else C.c_void_p(mask.ctypes.data), float(scale),
+                            C.c_void_p(out.raw_ptr() if code else out.data_ptr()), code, int(pitch or 0)))
     return out
 
 

@@ -272,6 +272,113 @@ __global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* 
     }
 }
 
+// ---- reader-side decode: raw integer payload -> float32 / complex64 (nsample, nchan, npol) -------------------------
+// What the reference's readers do on the host after `baseband` has unpacked a payload
+// (pulsarbat/readers/_baseband_readers.py:136-153: sideband conjugation + astype; :223-226, :268-275: axis
+// transposes / channel flip) done in the pass that unpacks it, so the raw bytes (1/4 .. 1/16 of the complex64
+// size) are what crosses PCIe.  The payload is addressed in place: the byte range of a file is a sequence of
+// blocks (header + payload, `blk_stride` apart) each holding `blk_t` time samples, and inside a payload element
+// (t, chan, pol) sits at element index e0 + t*st_t + chan*st_c + pol*st_p (strides may be negative: channel flip),
+// an element being 1 (real) or 2 (complex, re then im) components of `nbits` bits, low bits first in each byte.
+struct DecodeParams {
+    const unsigned char* raw;
+    int64_t first;       // first wanted time sample, in valid samples from the start of `raw`
+    int64_t blk_t;       // time samples per block
+    int64_t blk_stride;  // bytes from one block to the next
+    int64_t hdr;         // bytes from the start of a block to its payload
+    int64_t e0, st_t, st_c, st_p;
+    int nbits;           // 8 or 2
+    int code;            // nbits 8: 0 two's complement, 1 offset binary (v - 128); nbits 2: 4-level VDIF table
+    int lanes_t;         // consecutive lanes read consecutive time samples (else consecutive series)
+    int ls;              // log2 of the series per tile
+    int npol_shift;      // log2(npol), or -1
+    int pair16;          // 8-bit complex elements all at even addresses
+    float scale;
+    const unsigned char* conj;   // per series: negate the imaginary part (lower sideband); may be null
+    int64_t n;
+    int nchan, npol;
+    float* out;
+    int series_major;    // out[s*pitch + t] (time fastest) instead of out[t*S + s]
+    int64_t pitch;
+};
+
+__device__ __forceinline__ float decode_component(const unsigned char* pay, int64_t ci, int nbits, int code) {
+    if (nbits == 8) {
+        const int v = pay[ci];
+        return code ? (float)(v - 128) : (float)(signed char)v;
+    }
+    const int v = (pay[ci >> 2] >> (2 * (int)(ci & 3))) & 3;
+    const float mag = (v == 0 || v == 3) ? 3.3359f : 1.0f;   // optimal 4-level thresholds (VDIF / Mark 5 convention)
+    return (v & 2) ? mag : -mag;
+}
+
+// One workgroup unpacks a tile of 4096 elements, TS = 2^ls series by TT = 4096/TS time samples (TS = the series
+// count rounded up to a power of two, at most 64, so that no lanes idle when there are few series), through LDS:
+// consecutive lanes read along the payload's fastest axis and write along the output's.
+constexpr int kDecodeTile = 4096;
+constexpr int kDecodeLds = 5120;   // TS >= 4 rows are padded by one element
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
+    __shared__ float lds[NC][kDecodeLds];
+    const int ls = q.ls, TS = 1 << ls, lt = 12 - ls, TT = 1 << lt;
+    const int pitch = TS < 4 ? TS : TS + 1;
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    const int s0 = blockIdx.y * TS, S = q.nchan * q.npol;
+    const int64_t g0 = q.first + t0, blk0 = g0 / q.blk_t, w0 = g0 - blk0 * q.blk_t;   // uniform: once per workgroup
+    const bool one_wrap = q.blk_t >= TT;
+#pragma unroll
+    for (int j = 0; j < kDecodeTile / 256; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        const int tt = q.lanes_t ? (idx & (TT - 1)) : (idx >> ls), ss = q.lanes_t ? (idx >> lt) : (idx & (TS - 1));
+        const int s = s0 + ss;
+        if (t0 + tt < q.n && s < S) {
+            int64_t w = w0 + tt, blk = blk0;
+            if (w >= q.blk_t) {
+                if (one_wrap) {
+                    w -= q.blk_t;
+                    ++blk;
+                } else {
+                    const int64_t d = w / q.blk_t;
+                    blk += d;
+                    w -= d * q.blk_t;
+                }
+            }
+            const int c = q.npol_shift >= 0 ? (s >> q.npol_shift) : s / q.npol, p = s - c * q.npol;
+            const int64_t e = q.e0 + w * q.st_t + c * q.st_c + p * q.st_p;
+            const unsigned char* pay = q.raw + blk * q.blk_stride + q.hdr;
+            if (NC == 2 && q.pair16) {   // 8-bit complex at an even address: one 16-bit load
+                const int v = *reinterpret_cast<const unsigned short*>(pay + 2 * e);
+                const int re = v & 0xFF, im = v >> 8;
+                lds[0][tt * pitch + ss] = q.code ? (float)(re - 128) : (float)(signed char)re;
+                lds[NC - 1][tt * pitch + ss] = q.code ? (float)(im - 128) : (float)(signed char)im;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) lds[k][tt * pitch + ss] = decode_component(pay, e * NC + k, q.nbits, q.code);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kDecodeTile / 256; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        const int tt = q.series_major ? (idx & (TT - 1)) : (idx >> ls), ss = q.series_major ? (idx >> lt) : (idx & (TS - 1));
+        const int64_t t = t0 + tt;
+        const int s = s0 + ss;
+        if (t < q.n && s < S) {
+            const int64_t o = q.series_major ? (int64_t)s * q.pitch + t : t * S + s;
+            const float re = lds[0][tt * pitch + ss] * q.scale;
+            if (NC == 2) {
+                float im = lds[NC - 1][tt * pitch + ss] * q.scale;
+                if (q.conj && q.conj[s]) im = -im;
+                reinterpret_cast<float2*>(q.out)[o] = make_float2(re, im);
+            } else {
+                q.out[o] = re;
+            }
+        }
+    }
+}
+
 #ifndef PBH_F64
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the

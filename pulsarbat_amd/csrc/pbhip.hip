@@ -23,6 +23,7 @@
 #define pbh_decimate2 PBH_FN(decimate2)
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_transfer PBH_FN(transfer)
+#define pbh_decode PBH_FN(decode)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
@@ -850,6 +851,131 @@ int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHECK(direction == 0 ? xfer_h2d(dst, src, bytes, st) : xfer_d2h(dst, src, bytes, st));
+    return PBH_OK;
+}
+
+// Reader-side decode (include/pbhip.h): every byte the kernel will touch is bounds-checked here first.
+int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* L,
+               int64_t first, int64_t nsample, int nchan, int npol, const unsigned char* conj_mask, float scale,
+               void* out_dev, int out_layout, int64_t out_pitch) {
+    if (!L || (!raw && raw_bytes) || (!out_dev && nsample)) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample < 0 || first < 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "bad dimensions");
+    if (L->ncomp != 1 && L->ncomp != 2) return fail(PBH_ERR_INVALID, "ncomp must be 1 or 2");
+    if (!((L->nbits == 8 && (L->code == 0 || L->code == 1)) || (L->nbits == 2 && L->code == 0)))
+        return fail(PBH_ERR_UNSUPPORTED, "payload coding: 8 bits (code 0/1) or 2 bits");
+    if (L->blk_samples <= 0 || L->blk_stride < 0 || L->hdr_bytes < 0) return fail(PBH_ERR_INVALID, "bad block geometry");
+    if (out_layout != PBH_LAYOUT_SAMPLE_MAJOR && out_layout != PBH_LAYOUT_SERIES_MAJOR)
+        return fail(PBH_ERR_INVALID, "bad out_layout");
+    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nsample) return fail(PBH_ERR_INVALID, "out_pitch < nsample");
+    if ((int64_t)nchan * npol > 65535LL * 64) return fail(PBH_ERR_UNSUPPORTED, "too many series");
+    if (nsample == 0) return PBH_OK;
+    // extreme element indices inside a payload, and the blocks touched
+    const int64_t b0 = first / L->blk_samples, b1 = (first + nsample - 1) / L->blk_samples;
+    // [lo, hi]: element indices reached over time samples [ta, tb] of one payload
+    auto reach = [&](int64_t ta, int64_t tb, int64_t* lo, int64_t* hi) {
+        *lo = *hi = L->elem0;
+        auto span = [&](int64_t stride, int64_t a, int64_t b) {
+            *lo += stride >= 0 ? stride * a : stride * b;
+            *hi += stride >= 0 ? stride * b : stride * a;
+        };
+        span(L->stride_t, ta, tb);
+        span(L->stride_c, 0, nchan - 1);
+        span(L->stride_p, 0, npol - 1);
+    };
+    const int64_t bits = (int64_t)L->nbits * L->ncomp;
+    const int64_t t_first = first - b0 * L->blk_samples, t_last = first + nsample - 1 - b1 * L->blk_samples;
+    int64_t lo, hi, lo2, hi2;
+    reach(b1 > b0 ? 0 : t_first, t_last, &lo, &hi);   // the last block: what bounds the buffer
+    const int64_t pay_hi = ((hi + 1) * bits + 7) / 8;
+    if (b1 > b0) {                                      // earlier blocks are read up to their last sample
+        reach(b1 > b0 + 1 ? 0 : t_first, L->blk_samples - 1, &lo2, &hi2);
+        if (b1 > b0 + 1) {
+            int64_t lo3, hi3;
+            reach(t_first, L->blk_samples - 1, &lo3, &hi3);
+            lo2 = lo3 < lo2 ? lo3 : lo2;
+        }
+        if (L->hdr_bytes + ((hi2 + 1) * bits + 7) / 8 > L->blk_stride)
+            return fail(PBH_ERR_INVALID, "payload addressing overruns a block");
+        lo = lo2 < lo ? lo2 : lo;
+    }
+    if (lo < 0) return fail(PBH_ERR_INVALID, "payload addressing reaches before the payload");
+    if ((uint64_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) > (uint64_t)raw_bytes)
+        return fail(PBH_ERR_INVALID, "raw buffer too short for the requested samples");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    void *sraw = nullptr, *sconj = nullptr;
+    auto cleanup = [&] {
+        if (sraw) hipFree(sraw);
+        if (sconj) hipFree(sconj);
+    };
+    const unsigned char* draw = (const unsigned char*)raw;
+    int rc = PBH_OK;
+    if (raw_loc == PBH_HOST) {
+        // only the blocks that are read travel
+        const size_t off = (size_t)(b0 * L->blk_stride), len = (size_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) - off;
+        if ((rc = dev_alloc(nullptr, &sraw, len)) != PBH_OK) return rc;
+        if (xfer_h2d(sraw, (const char*)raw + off, len, st) != hipSuccess) {
+            cleanup();
+            return fail(PBH_ERR_HIP, "pbh_decode: host -> device copy failed");
+        }
+        draw = (const unsigned char*)sraw - off;   // (only offsets >= off are formed)
+    }
+    bool any_conj = false;
+    if (conj_mask && L->ncomp == 2)
+        for (int64_t i = 0; i < (int64_t)nchan * npol; ++i) any_conj |= conj_mask[i] != 0;
+    if (any_conj) {
+        if ((rc = dev_alloc(nullptr, &sconj, (size_t)nchan * npol)) != PBH_OK) {
+            cleanup();
+            return rc;
+        }
+        if (xfer_h2d(sconj, conj_mask, (size_t)nchan * npol, st) != hipSuccess) {
+            cleanup();
+            return fail(PBH_ERR_HIP, "pbh_decode: mask copy failed");
+        }
+    }
+    DecodeParams q;
+    q.raw = draw;
+    q.first = first;
+    q.blk_t = L->blk_samples;
+    q.blk_stride = L->blk_stride;
+    q.hdr = L->hdr_bytes;
+    q.e0 = L->elem0;
+    q.st_t = L->stride_t;
+    q.st_c = L->stride_c;
+    q.st_p = L->stride_p;
+    q.nbits = L->nbits;
+    q.code = L->code;
+    const int64_t at = L->stride_t < 0 ? -L->stride_t : L->stride_t;
+    const int64_t ac = L->stride_c < 0 ? -L->stride_c : L->stride_c, ap = L->stride_p < 0 ? -L->stride_p : L->stride_p;
+    const int64_t as = (nchan > 1 && npol > 1) ? (ac < ap ? ac : ap) : (nchan > 1 ? ac : (npol > 1 ? ap : INT64_MAX));
+    q.lanes_t = at <= as;
+    q.scale = scale;
+    q.conj = (const unsigned char*)sconj;
+    q.n = nsample;
+    q.nchan = nchan;
+    q.npol = npol;
+    q.out = (float*)out_dev;
+    q.series_major = out_layout == PBH_LAYOUT_SERIES_MAJOR;
+    q.pitch = out_pitch;
+    const int64_t S = (int64_t)nchan * npol;
+    q.ls = 0;
+    while (q.ls < 6 && (1 << q.ls) < S) ++q.ls;
+    q.npol_shift = is_pow2(npol) ? ilog2(npol) : -1;
+    q.pair16 = L->nbits == 8 && L->ncomp == 2 && L->blk_stride % 2 == 0 && L->hdr_bytes % 2 == 0 &&
+               ((uintptr_t)draw) % 2 == 0;
+    const int TS = 1 << q.ls, TT = kDecodeTile / TS;
+    const dim3 grid((unsigned)((nsample + TT - 1) / TT), (unsigned)((S + TS - 1) / TS));
+    if (L->ncomp == 2)
+        hipLaunchKernelGGL(k_decode<2>, grid, dim3(256), 0, st, q);
+    else
+        hipLaunchKernelGGL(k_decode<1>, grid, dim3(256), 0, st, q);
+    hipError_t e = hipGetLastError();
+    if (sraw || sconj) {   // staging is freed below: the kernel must be done with it
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e2;
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_decode: ") + hipGetErrorString(e));
     return PBH_OK;
 }
 

@@ -23,6 +23,8 @@
     int P##pol_basis(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##transfer(int, void*, void*, const void*, size_t, int);                                               \
+    int P##decode(int, void*, const void*, size_t, int, const pbh_raw_layout_t*, int64_t, int64_t, int, int,    \
+                  const unsigned char*, float, void*, int, int64_t);                                            \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
@@ -139,6 +141,12 @@ int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double
 }
 int pbh_dedisperse(pbh_plan* p, const void* in, void* out, int il, int ol) {
     FORWARD(p, pbh32_dedisperse(P32(p), in, out, il, ol), pbh64_dedisperse(P64(p), in, out, il, ol));
+}
+int pbh_decode(int device, void* stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* layout,
+               int64_t first, int64_t nsample, int nchan, int npol, const unsigned char* conj_mask, float scale, void* out,
+               int out_layout, int64_t out_pitch) {
+    return done(PBH_C64, pbh32_decode(device, stream, raw, raw_bytes, raw_loc, layout, first, nsample, nchan, npol, conj_mask,
+                                      scale, out, out_layout, out_pitch));
 }
 int pbh_transfer(int device, void* stream, void* dst, const void* src, size_t bytes, int direction) {
     return done(PBH_C64, pbh32_transfer(device, stream, dst, src, bytes, direction));

@@ -1,0 +1,289 @@
+"""Readers: the base class (reference tests/test_readers.py), the host-side format parsing and the device decode
+of the baseband readers (reference tests/test_baseband_readers.py, whose data files are tests/golden/readers)."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import pulsarbat_amd as pb
+import pulsarbat_amd.readers as pbr
+from pulsarbat_amd import units as u
+from pulsarbat_amd import Time
+from pulsarbat_amd.readers._formats import open_raw
+from oracle import reader_oracle as ro
+from oracle import dedisp_oracle as orc
+
+DATA = Path(__file__).parent / "golden" / "readers"
+GUPPI = sorted(DATA.glob("fake.*.raw"))
+
+
+class IndexReader(pbr.BaseReader):
+    """Sample k of the stream has the value k (reference tests/test_readers.py:11-38)."""
+
+    def __init__(self, /, *, shape, dtype=np.int32, sample_rate=1 * u.Hz, start_time=None, signal_type=pb.Signal, **kw):
+        super().__init__(signal_type=signal_type, shape=shape, dtype=dtype, sample_rate=sample_rate,
+                         start_time=start_time, **kw)
+
+    def _read_array(self, offset, n, /):
+        x = np.arange(offset, offset + n).reshape((-1,) + (self.ndim - 1) * (1,))
+        return (x * np.ones(self.sample_shape)).astype(self.dtype)
+
+
+class TestBaseReader:
+    def test_basic_functionality(self):
+        shape, dtype, t0, SR = (100, 4), np.uint16, Time.now(), 1 * u.Hz
+        r = IndexReader(shape=shape, dtype=dtype, sample_rate=SR, start_time=t0)
+        assert repr(r) and str(r) and dir(r)
+        assert r.shape == shape and len(r) == 100 and r.ndim == 2 and r.sample_shape == (4,) and r.dtype == dtype
+        assert u.isclose(SR, r.sample_rate) and u.isclose(1 / SR, r.dt) and u.isclose(100 / SR, r.time_length)
+        assert t0.isclose(r.start_time) and (t0 + 100 / SR).isclose(r.stop_time)
+        assert r.offset_at(t0) == 0 and r.offset_at(r.stop_time) == len(r)
+        t = r.time_at(60, unit=u.s)
+        assert u.isclose(t, 60 * u.s)
+        for offset, n in [(0, 1), (4, 10), (10, 49)]:
+            assert r.offset_at(offset / SR) == offset
+            assert r.time_at(offset).isclose(t0 + offset / SR)
+            x = r.read(offset, n)
+            assert type(x) is pb.Signal and x.dtype == dtype and x.sample_shape == r.sample_shape
+            assert np.allclose(np.array(x), np.arange(offset, offset + n)[:, None])
+            assert x.start_time.isclose(t0 + offset / SR)
+        for bad in [r.start_time - 10 * u.s, r.stop_time + 10 * u.s]:
+            with pytest.raises(EOFError):
+                r.offset_at(bad)
+        with pytest.raises(EOFError):
+            r.read(99, 2)
+        with pytest.raises(ValueError):
+            r.read(-1, 10)
+        with pytest.raises(ValueError):
+            r.read(10, -1)
+
+    def test_contains(self):
+        t0 = Time("2020-01-01T12:34:56.000", format="isot", precision=9)
+        ts = [t0 + k * u.s for k in range(-2, 6)]
+        r = IndexReader(shape=(4,), dtype=np.uint16, sample_rate=1 * u.Hz, start_time=t0)
+        assert t0 + 2 * u.s in r
+        assert list(r.contains(ts)) == [0, 0, 1, 1, 1, 1, 0, 0]
+        r = IndexReader(shape=(4,), dtype=np.uint16, sample_rate=1 * u.Hz)
+        assert not (t0 + 2 * u.s in r)
+        assert list(r.contains(ts)) == [0] * 8
+
+    @pytest.mark.parametrize("sigtype, dtype, shape, sigkw", [
+        (pb.DualPolarizationSignal, np.complex64, (1024, 4, 2), {"center_freq": 1 * u.GHz, "pol_type": "linear"}),
+        (pb.FullStokesSignal, np.float64, (1024, 4, 4), {"center_freq": 1 * u.GHz, "chan_bw": 1 * u.MHz}),
+    ])
+    def test_extra_functionality(self, sigtype, dtype, shape, sigkw):
+        r = IndexReader(shape=shape, dtype=dtype, sample_rate=1 * u.MHz, start_time=None, signal_type=sigtype, **sigkw)
+        assert r.start_time is None and r.stop_time is None
+        x = r.read(5, 17)
+        assert type(x) is sigtype and u.isclose(x.center_freq, sigkw["center_freq"]) and x.start_time is None
+        y = r.read(5, 17, use_dask=True)       # the reference's dask keyword is accepted
+        assert np.allclose(np.array(x), np.array(y))
+
+    def test_bad_arguments(self):
+        with pytest.raises(ValueError):
+            IndexReader(shape=())
+        with pytest.raises(ValueError):
+            IndexReader(shape=(100,), signal_type=np.ndarray)
+        for SR in (-5 * u.MHz, "fish", u.Quantity([10, 20], u.Hz)):
+            with pytest.raises(ValueError):
+                IndexReader(shape=(100,), sample_rate=SR)
+        for t0 in (1 * u.s, "fish", [424.23, 23424.42]):
+            with pytest.raises(ValueError):
+                IndexReader(shape=(100,), start_time=t0)
+
+    def test_broken_reader(self):
+        class BrokenReader(pbr.BaseReader):
+            def __init__(self, /, *, shape=(100,), dtype=np.int32, N=0):
+                self._N = N
+                super().__init__(shape=shape, dtype=dtype, sample_rate=1 * u.Hz)
+
+            def _read_array(self, offset, n, /):
+                return np.zeros(self._N, dtype=np.int32)
+
+        for kw in (dict(dtype=np.float64), dict(shape=(100, 4, 2)), dict(N=10)):
+            with pytest.raises(ValueError):
+                BrokenReader(**kw)
+
+
+# ---- host-side format parsing (no GPU): metadata the reference's tests assert, and the addressing contract -------
+class TestFormats:
+    def test_metadata(self):
+        r = open_raw(DATA / "sample.vdif")
+        assert (r.fmt, r.nsample, r.sample_shape, r.complex_data, r.nbits) == ("vdif", 40000, (8, 1), False, 2)
+        assert r.start_time.isclose(Time("2014-06-16T05:56:07.000", format="isot")) and u.isclose(r.sample_rate, 32 * u.MHz)
+        r = open_raw(DATA / "sample.dada")
+        assert (r.fmt, r.nsample, r.sample_shape, r.complex_data) == ("dada", 16000, (2, 1), True)
+        assert r.start_time.isclose(Time("2013-07-02T01:39:20.000", format="isot")) and u.isclose(r.sample_rate, 16 * u.MHz)
+        r = open_raw(GUPPI)
+        assert (r.fmt, r.nsample, r.sample_shape) == ("guppi", 8192 * 4, (2, 4))
+        assert r.start_time.isclose(Time("1997-07-11T12:34:56.000", format="isot")) and u.isclose(r.sample_rate, 3.125 * u.MHz)
+        r2 = open_raw(GUPPI[2])
+        assert r2.start_time.isclose(r.start_time + 16384 / r.sample_rate)
+
+    @pytest.mark.parametrize("name,whole", [("sample.dada", ro.dada_samples), ("stokes_ef.dada", ro.dada_samples),
+                                            ("sample.vdif", ro.vdif_samples), ("guppi", ro.guppi_samples)])
+    def test_addressing_contract(self, name, whole):
+        """fetch() + layout() describe the same samples as a whole-file numpy unpacking of the format."""
+        path = GUPPI if name == "guppi" else DATA / name
+        r = open_raw(path)
+        want = whole(path)
+        assert want.shape == (r.nsample,) + r.sample_shape
+        for offset, n in [(0, min(64, r.nsample)), (r.nsample // 3, min(2500, r.nsample - r.nsample // 3)), (r.nsample - 5, 5)]:
+            buf, first = r.fetch(offset, n)
+            got = ro.unpack_general(buf, r.layout(), first, n, *r.sample_shape)
+            assert np.array_equal(got, want[offset:offset + n])
+
+    def test_reader_construction_needs_no_gpu(self):
+        r = pbr.BasebandReader(DATA / "sample.vdif")
+        assert r.shape == (20000, 8) and r.dtype == np.complex64 and r.real_baseband
+        assert pbr.BasebandReader(DATA / "sample.vdif", squeeze=False).shape == (20000, 8, 1)
+        r = pbr.BasebandReader(DATA / "sample.dada")
+        assert r.shape == (16000, 2) and not r.real_baseband
+        assert pbr.BasebandReader(DATA / "sample.dada", squeeze=False).shape == (16000, 2, 1)
+        with pytest.raises(ValueError):
+            pbr.BasebandReader(DATA / "sample.vdif", lower_sideband=[True, False])
+        r = pbr.GUPPIRawReader(GUPPI)
+        assert len(r) == 8192 * 4 and r.sample_shape == (4, 2) and r.pol_type == "linear"
+        assert u.isclose(r.center_freq, 344.1875 * u.MHz) and r.lower_sideband is False
+        r = pbr.DADAStokesReader(DATA / "stokes_ef.dada")
+        assert r.shape == (16, 2048, 4) and r.dtype == np.float32 and r.lower_sideband is True and r.freq_align == "top"
+        with pytest.raises(ValueError):
+            pbr.DADAStokesReader(DATA / "sample.dada")
+
+    def test_intensity_constraints(self):
+        """reference tests/test_baseband_readers.py:63-86"""
+        with pytest.raises(ValueError):
+            pbr.BasebandReader(DATA / "sample.dada", intensity=True)
+        kw = dict(center_freq=1.4 * u.GHz, chan_bw=16 * u.MHz)
+        assert pbr.BasebandReader(DATA / "sample.vdif", signal_kwargs=kw, signal_type=pb.IntensitySignal).intensity
+        with pytest.raises(ValueError):
+            pbr.BasebandReader(DATA / "sample.vdif", signal_kwargs=kw, signal_type=pb.IntensitySignal, intensity=False)
+        kw = dict(center_freq=1.4 * u.GHz)
+        assert not pbr.BasebandReader(DATA / "sample.vdif", signal_kwargs=kw, signal_type=pb.BasebandSignal).intensity
+        with pytest.raises(ValueError):
+            pbr.BasebandReader(DATA / "sample.vdif", signal_kwargs=kw, signal_type=pb.BasebandSignal, intensity=True)
+
+    def test_read_without_gpu_fails_loudly(self):
+        from pulsarbat_amd import _hip
+        if _hip.available():
+            pytest.skip("a GPU is present")
+        with pytest.raises(_hip.HipUnavailableError):
+            pbr.BasebandReader(DATA / "sample.dada").read(0, 16)
+
+
+# ---- device decode ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+class TestDeviceDecode:
+    def test_dada(self):
+        r = pbr.BasebandReader(DATA / "sample.dada")
+        want = ro.dada_samples(DATA / "sample.dada")[:, :, 0]
+        z = r.read(0, 16)
+        assert type(z.data) is pb.DeviceArray and u.isclose(z.sample_rate, 16 * u.MHz)
+        assert np.array_equal(np.asarray(z), want[:16])
+        z = r.read(1234, 10000)
+        assert np.array_equal(np.asarray(z), want[1234:11234]) and z.start_time.isclose(r.time_at(1234))
+        z = pbr.BasebandReader(DATA / "sample.dada", squeeze=False).read(15990, 10)
+        assert z.shape == (10, 2, 1) and np.array_equal(np.asarray(z)[:, :, 0], want[15990:])
+
+    def test_sideband(self):
+        """reference tests/test_baseband_readers.py:46-61 (on the real-sampled VDIF file) and on complex data"""
+        for name in ("sample.vdif", "sample.dada"):
+            nser = 8 if name.endswith("vdif") else 2
+            z1 = np.asarray(pbr.BasebandReader(DATA / name, lower_sideband=False).read(0, 16))
+            z2 = np.asarray(pbr.BasebandReader(DATA / name, lower_sideband=True).read(0, 16))
+            assert np.allclose(z1, z2.conj()) and np.abs(z1.imag).max() > 0
+            lsb = (np.arange(nser) % 3).astype(bool)
+            z3 = np.asarray(pbr.BasebandReader(DATA / name, lower_sideband=lsb).read(0, 16))
+            assert np.allclose(z1[:, ~lsb], z3[:, ~lsb]) and np.allclose(z1[:, lsb], z3[:, lsb].conj())
+
+    def test_vdif_real_baseband(self):
+        r = pbr.BasebandReader(DATA / "sample.vdif")
+        z = r.read(0, 20000)
+        assert z.shape == (20000, 8) and z.dtype == np.complex64 and u.isclose(z.sample_rate, 16 * u.MHz)
+        x = ro.vdif_samples(DATA / "sample.vdif")[:, :, 0]
+        want = orc.real_to_complex(x, axis=0)
+        assert np.linalg.norm(np.asarray(z) - want) / np.linalg.norm(want) < 1e-5
+        z = r.read(5000, 4096)        # spans the boundary between the two frame sets of the file
+        want = orc.real_to_complex(x[10000:10000 + 8192], axis=0)
+        assert np.linalg.norm(np.asarray(z) - want) / np.linalg.norm(want) < 1e-5
+
+    @pytest.mark.parametrize("series_major", [False, True])
+    def test_guppi(self, series_major):
+        """reference tests/test_baseband_readers.py:89-124"""
+        r = pbr.GUPPIRawReader(GUPPI, series_major=series_major)
+        want = ro.guppi_samples(GUPPI).transpose(0, 2, 1)
+        z = r.read(0, 8)
+        assert len(z) == 8 and type(z) is pb.DualPolarizationSignal and z.pol_type == "linear"
+        assert u.isclose(z.sample_rate, 3.125 * u.MHz) and u.isclose(z.center_freq, 344.1875 * u.MHz)
+        assert u.isclose(z.bandwidth, 12.5 * u.MHz)
+        assert z.start_time.isclose(Time("1997-07-11T12:34:56.000", format="isot"))
+        assert np.array_equal(np.asarray(z), want[:8])
+        z1 = r.read(16384 + 16, 32)
+        z2 = pbr.GUPPIRawReader(GUPPI[2]).read(16, 32)
+        assert np.array_equal(np.asarray(z1), np.asarray(z2)) and z1.start_time.isclose(z2.start_time)
+        z = r.read(1000, 20000)       # many blocks, both files' boundaries
+        assert np.array_equal(np.asarray(z), want[1000:21000])
+        if series_major:
+            assert z.data.series_major_pitch() is not None
+
+    def test_guppi_into_dedispersion(self):
+        """The reader's series-major output is what coherent_dedispersion takes without layout passes."""
+        r = pbr.GUPPIRawReader(GUPPI, series_major=True)
+        z = r.read(0, 1 << 14)
+        y = pb.coherent_dedispersion(z, pb.DM(0.5))
+        x = ro.guppi_samples(GUPPI).transpose(0, 2, 1)[:1 << 14]
+        yr, s0, s1 = orc.coherent_dedispersion(x, 0.5, 3.125e6, 344.1875e6)
+        assert y.shape == yr.shape
+        assert np.linalg.norm(np.asarray(y) - yr) / np.linalg.norm(yr) < 1e-5
+
+    def test_dada_stokes(self):
+        """reference tests/test_baseband_readers.py:127-141"""
+        r = pbr.DADAStokesReader(DATA / "stokes_ef.dada")
+        z = r.read(0, 4)
+        assert type(z) is pb.FullStokesSignal and z.nchan == 2048 and z.freq_align == "top"
+        assert u.isclose(z.center_freq, 7 * u.GHz) and u.isclose(z.bandwidth, 2 * u.GHz) and u.isclose(z.dt, 131072 * u.ns)
+        want = np.flip(ro.dada_samples(DATA / "stokes_ef.dada"), axis=-1).transpose(0, 2, 1)
+        assert np.array_equal(np.asarray(r.read(3, 13)), want[3:16])
+
+    @pytest.mark.parametrize("nbits,ncomp,code", [(8, 2, 0), (8, 2, 1), (8, 1, 0), (2, 1, 0), (2, 2, 0)])
+    @pytest.mark.parametrize("series_major", [False, True])
+    def test_synthetic_layouts(self, nbits, ncomp, code, series_major):
+        """Random bytes through blocked, headered, strided and flipped layouts: bit-exact against the numpy
+        statement of the addressing contract."""
+        from pulsarbat_amd import _hip
+        rng = np.random.default_rng(nbits * 10 + ncomp + code)
+        nchan, npol, blk_t, nblk, hdr = 5, 2, 1000, 7, 96
+        per_byte = 8 // (nbits * ncomp) if nbits * ncomp < 8 else 1
+        ebytes = max(nbits * ncomp // 8, 1)
+        pay = blk_t * nchan * npol * ebytes // per_byte
+        stride = hdr + pay + 40
+        raw = rng.integers(0, 256, nblk * stride, dtype=np.uint8)
+        cases = [dict(elem0=0, stride_t=nchan * npol, stride_c=npol, stride_p=1),                      # sample-major payload
+                 dict(elem0=0, stride_t=npol, stride_c=blk_t * npol, stride_p=1),                      # GUPPI-like
+                 dict(elem0=(nchan - 1) * blk_t, stride_t=1, stride_c=-blk_t, stride_p=nchan * blk_t)]  # planar, channels flipped
+        for c in cases:
+            lay = dict(nbits=nbits, ncomp=ncomp, code=code, blk_samples=blk_t, blk_stride=stride, hdr_bytes=hdr, **c)
+            for first, n in [(0, 64), (937, 4500), (blk_t * nblk - 130, 130)]:
+                conj = rng.integers(0, 2, (nchan, npol)).astype(bool) if ncomp == 2 else None
+                got = _hip.decode(raw, lay, first, n, nchan, npol, conj=conj, scale=0.5, series_major=series_major)
+                want = ro.unpack_general(raw, lay, first, n, nchan, npol) * np.float32(0.5)
+                if conj is not None:
+                    want = np.where(conj[None], want.conj(), want)
+                assert got.shape == (n, nchan, npol) and np.array_equal(np.asarray(got), want)
+                assert (got.series_major_pitch() is not None) == series_major
+
+    def test_decode_bounds_checked(self):
+        from pulsarbat_amd import _hip
+        raw = np.zeros(1000, np.uint8)
+        lay = dict(nbits=8, ncomp=2, code=0, blk_samples=100, blk_stride=400, hdr_bytes=0, elem0=0, stride_t=2, stride_c=1, stride_p=1)
+        _hip.decode(raw, lay, 0, 250, 2, 1)
+        errors = (ValueError, NotImplementedError, _hip.HipError)
+        with pytest.raises(errors):
+            _hip.decode(raw, lay, 0, 251, 2, 1)          # one sample past the buffer
+        with pytest.raises(errors):
+            _hip.decode(raw, dict(lay, elem0=-1), 0, 10, 2, 1)
+        with pytest.raises(errors):
+            _hip.decode(raw, dict(lay, stride_t=3), 0, 150, 2, 1)   # a block's samples overrun into the next block
+        with pytest.raises(errors):
+            _hip.decode(raw, dict(lay, nbits=4), 0, 10, 2, 1)
