@@ -213,6 +213,15 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
                const pbh_raw_layout_t* layout, int64_t first, int64_t nsample, int nchan, int npol,
                const unsigned char* conj_mask, float scale, void* out_dev, int out_layout, int64_t out_pitch);
 
+/* pbh_dedisperse_stream fed with RAW payload bytes (pbh_raw_layout_t, complex samples): chunk k decodes samples
+ * [first + k*hop, first + k*hop + nsample) of the payload stream on the device (pbh_decode's unpacking, conjugation mask and
+ * scale) and dedisperses them, so that 2 bytes per 8-bit complex sample cross PCIe instead of 8.  The result
+ * equals pbh_dedisperse_stream on the decoded array.  complex64 plans only.                                */
+int pbh_dedisperse_stream_raw(pbh_plan* plan, const void* host_raw, size_t raw_bytes,
+                              const pbh_raw_layout_t* layout, int64_t first, int64_t total_nsample,
+                              const unsigned char* conj_mask, float scale, void* host_out,
+                              int64_t* nchunk, float* ms_total);
+
 /* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
 int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nsample,
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);

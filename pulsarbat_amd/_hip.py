@@ -87,6 +87,9 @@ SIGNATURES = {
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_float)]),
+    "pbh_dedisperse_stream_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_RawLayout), C.c_int64, C.c_int64,
+                                            C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_float)]),
     "pbh_detect": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                              C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
@@ -353,6 +356,29 @@ class Plan:
         n, ms = C.c_int64(), C.c_float()
         _check(lib().pbh_dedisperse_stream(self._h, C.c_void_p(x_host.ctypes.data), int(x_host.shape[0]),
                                            C.c_void_p(out.ctypes.data), C.byref(n), C.byref(ms)))
+        assert n.value == nchunk
+        return out, float(ms.value)
+
+    def dedisperse_stream_raw(self, raw, layout, total_nsample, first=0, conj=None, scale=1.0, out=None):
+        """``dedisperse_stream`` fed with raw payload bytes (uint8 numpy array + ``pbh_raw_layout_t`` fields):
+        decode on the device, chunk by chunk.  Returns ((nchunk*hop, nchan, npol) complex64, ms)."""
+        if not isinstance(raw, np.ndarray) or raw.dtype != np.uint8 or not raw.flags.c_contiguous:
+            raise TypeError("dedisperse_stream_raw needs a C-contiguous uint8 numpy array")
+        hop = self.nout
+        if hop <= 0 or total_nsample < self.nsample:
+            raise ValueError("empty valid region or input shorter than one chunk")
+        nchunk = (int(total_nsample) - self.nsample) // hop + 1
+        if out is None:
+            out = np.empty((nchunk * hop, self.nchan, self.npol), dtype=np.complex64)
+        lay = _RawLayout(**{k: int(v) for k, v in layout.items()})
+        mask = None
+        if conj is not None:
+            mask = np.ascontiguousarray(np.broadcast_to(np.asarray(conj, dtype=bool), (self.nchan, self.npol)), dtype=np.uint8)
+        self._sync_stream()
+        n, ms = C.c_int64(), C.c_float()
+        _check(lib().pbh_dedisperse_stream_raw(self._h, C.c_void_p(raw.ctypes.data), raw.size, C.byref(lay),
+                                               int(first), int(total_nsample), None if mask is None else C.c_void_p(mask.ctypes.data),
+                                               float(scale), C.c_void_p(out.ctypes.data), C.byref(n), C.byref(ms)))
         assert n.value == nchunk
         return out, float(ms.value)
 

@@ -24,6 +24,7 @@
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_transfer PBH_FN(transfer)
 #define pbh_decode PBH_FN(decode)
+#define pbh_dedisperse_stream_raw PBH_FN(dedisperse_stream_raw)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
@@ -855,21 +856,20 @@ int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_
 }
 
 // Reader-side decode (include/pbhip.h): every byte the kernel will touch is bounds-checked here first.
-int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* L,
-               int64_t first, int64_t nsample, int nchan, int npol, const unsigned char* conj_mask, float scale,
-               void* out_dev, int out_layout, int64_t out_pitch) {
-    if (!L || (!raw && raw_bytes) || (!out_dev && nsample)) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (nsample < 0 || first < 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "bad dimensions");
+struct DecodeSpan {
+    int64_t b0, b1;     // first / last block touched
+    size_t off, len;    // byte range [off, off + len) of the raw buffer that is read
+};
+
+static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan, int npol, size_t raw_bytes,
+                       DecodeSpan* sp) {
+    if (!L) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || first < 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "bad dimensions");
     if (L->ncomp != 1 && L->ncomp != 2) return fail(PBH_ERR_INVALID, "ncomp must be 1 or 2");
     if (!((L->nbits == 8 && (L->code == 0 || L->code == 1)) || (L->nbits == 2 && L->code == 0)))
         return fail(PBH_ERR_UNSUPPORTED, "payload coding: 8 bits (code 0/1) or 2 bits");
     if (L->blk_samples <= 0 || L->blk_stride < 0 || L->hdr_bytes < 0) return fail(PBH_ERR_INVALID, "bad block geometry");
-    if (out_layout != PBH_LAYOUT_SAMPLE_MAJOR && out_layout != PBH_LAYOUT_SERIES_MAJOR)
-        return fail(PBH_ERR_INVALID, "bad out_layout");
-    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nsample) return fail(PBH_ERR_INVALID, "out_pitch < nsample");
     if ((int64_t)nchan * npol > 65535LL * 64) return fail(PBH_ERR_UNSUPPORTED, "too many series");
-    if (nsample == 0) return PBH_OK;
-    // extreme element indices inside a payload, and the blocks touched
     const int64_t b0 = first / L->blk_samples, b1 = (first + nsample - 1) / L->blk_samples;
     // [lo, hi]: element indices reached over time samples [ta, tb] of one payload
     auto reach = [&](int64_t ta, int64_t tb, int64_t* lo, int64_t* hi) {
@@ -901,38 +901,22 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
     if (lo < 0) return fail(PBH_ERR_INVALID, "payload addressing reaches before the payload");
     if ((uint64_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) > (uint64_t)raw_bytes)
         return fail(PBH_ERR_INVALID, "raw buffer too short for the requested samples");
-    HIPCHECK(hipSetDevice(device));
-    hipStream_t st = (hipStream_t)hip_stream;
-    void *sraw = nullptr, *sconj = nullptr;
-    auto cleanup = [&] {
-        if (sraw) hipFree(sraw);
-        if (sconj) hipFree(sconj);
-    };
-    const unsigned char* draw = (const unsigned char*)raw;
-    int rc = PBH_OK;
-    if (raw_loc == PBH_HOST) {
-        // only the blocks that are read travel
-        const size_t off = (size_t)(b0 * L->blk_stride), len = (size_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) - off;
-        if ((rc = dev_alloc(nullptr, &sraw, len)) != PBH_OK) return rc;
-        if (xfer_h2d(sraw, (const char*)raw + off, len, st) != hipSuccess) {
-            cleanup();
-            return fail(PBH_ERR_HIP, "pbh_decode: host -> device copy failed");
-        }
-        draw = (const unsigned char*)sraw - off;   // (only offsets >= off are formed)
-    }
-    bool any_conj = false;
-    if (conj_mask && L->ncomp == 2)
-        for (int64_t i = 0; i < (int64_t)nchan * npol; ++i) any_conj |= conj_mask[i] != 0;
-    if (any_conj) {
-        if ((rc = dev_alloc(nullptr, &sconj, (size_t)nchan * npol)) != PBH_OK) {
-            cleanup();
-            return rc;
-        }
-        if (xfer_h2d(sconj, conj_mask, (size_t)nchan * npol, st) != hipSuccess) {
-            cleanup();
-            return fail(PBH_ERR_HIP, "pbh_decode: mask copy failed");
-        }
-    }
+    sp->b0 = b0;
+    sp->b1 = b1;
+    // the range starts at the lowest element read in the first block (a long time-major payload is one block:
+    // only the wanted samples travel), rounded down to 16 bytes
+    int64_t lo_first, hi_first;
+    reach(t_first, b1 > b0 ? L->blk_samples - 1 : t_last, &lo_first, &hi_first);
+    const int64_t skip = (L->hdr_bytes + lo_first * bits / 8) & ~(int64_t)15;
+    sp->off = (size_t)(b0 * L->blk_stride + skip);
+    sp->len = (size_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) - sp->off;
+    return PBH_OK;
+}
+
+// draw: device address that byte 0 of the raw buffer would have (only offsets inside the checked span are formed)
+static int decode_launch(const unsigned char* draw, const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan,
+                         int npol, const unsigned char* dconj, float scale, void* out_dev, int out_layout,
+                         int64_t out_pitch, hipStream_t st) {
     DecodeParams q;
     q.raw = draw;
     q.first = first;
@@ -950,7 +934,7 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
     const int64_t as = (nchan > 1 && npol > 1) ? (ac < ap ? ac : ap) : (nchan > 1 ? ac : (npol > 1 ? ap : INT64_MAX));
     q.lanes_t = at <= as;
     q.scale = scale;
-    q.conj = (const unsigned char*)sconj;
+    q.conj = dconj;
     q.n = nsample;
     q.nchan = nchan;
     q.npol = npol;
@@ -969,12 +953,57 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
         hipLaunchKernelGGL(k_decode<2>, grid, dim3(256), 0, st, q);
     else
         hipLaunchKernelGGL(k_decode<1>, grid, dim3(256), 0, st, q);
-    hipError_t e = hipGetLastError();
-    if (sraw || sconj) {   // staging is freed below: the kernel must be done with it
-        hipError_t e2 = hipStreamSynchronize(st);
-        if (e == hipSuccess) e = e2;
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* L,
+               int64_t first, int64_t nsample, int nchan, int npol, const unsigned char* conj_mask, float scale,
+               void* out_dev, int out_layout, int64_t out_pitch) {
+    if (!L || (!raw && raw_bytes) || (!out_dev && nsample)) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample < 0) return fail(PBH_ERR_INVALID, "bad dimensions");
+    if (out_layout != PBH_LAYOUT_SAMPLE_MAJOR && out_layout != PBH_LAYOUT_SERIES_MAJOR)
+        return fail(PBH_ERR_INVALID, "bad out_layout");
+    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nsample) return fail(PBH_ERR_INVALID, "out_pitch < nsample");
+    if (nsample == 0) return PBH_OK;
+    DecodeSpan sp;
+    PBHCHECK(decode_span(L, first, nsample, nchan, npol, raw_bytes, &sp));
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    void *sraw = nullptr, *sconj = nullptr;
+    auto cleanup = [&] {
+        if (sraw) hipFree(sraw);
+        if (sconj) hipFree(sconj);
+    };
+    const unsigned char* draw = (const unsigned char*)raw;
+    int rc = PBH_OK;
+    if (raw_loc == PBH_HOST) {   // only the blocks that are read travel
+        if ((rc = dev_alloc(nullptr, &sraw, sp.len)) != PBH_OK) return rc;
+        if (xfer_h2d(sraw, (const char*)raw + sp.off, sp.len, st) != hipSuccess) {
+            cleanup();
+            return fail(PBH_ERR_HIP, "pbh_decode: host -> device copy failed");
+        }
+        draw = (const unsigned char*)sraw - sp.off;
     }
+    bool any_conj = false;
+    if (conj_mask && L->ncomp == 2)
+        for (int64_t i = 0; i < (int64_t)nchan * npol; ++i) any_conj |= conj_mask[i] != 0;
+    if (any_conj) {
+        if ((rc = dev_alloc(nullptr, &sconj, (size_t)nchan * npol)) != PBH_OK) {
+            cleanup();
+            return rc;
+        }
+        if (xfer_h2d(sconj, conj_mask, (size_t)nchan * npol, st) != hipSuccess) {
+            cleanup();
+            return fail(PBH_ERR_HIP, "pbh_decode: mask copy failed");
+        }
+    }
+    rc = decode_launch(draw, L, first, nsample, nchan, npol, (const unsigned char*)sconj, scale, out_dev, out_layout,
+                       out_pitch, st);
+    hipError_t e = hipSuccess;
+    if (sraw || sconj) e = hipStreamSynchronize(st);   // staging is freed below: the kernel must be done with it
     cleanup();
+    if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_decode: ") + hipGetErrorString(e));
     return PBH_OK;
 }
@@ -2162,6 +2191,138 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsampl
     if (s_out) hipStreamDestroy(s_out);
     if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
     return rc;
+}
+
+// The same overlap-save stream fed with RAW payload bytes (reader-side decode in front): per chunk only the bytes
+// of the blocks that hold its samples cross PCIe (2 bytes per 8-bit complex sample instead of 8), k_decode
+// writes them series-major on the device, and the chunk runs the pipeline without its de-interleave pass.
+int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_bytes, const pbh_raw_layout_t* L,
+                              int64_t first, int64_t total_nsample, const unsigned char* conj_mask, float scale, void* host_out,
+                              int64_t* nchunk_out, float* ms_total) {
+    if (!p || !host_raw || !host_out || !L) return fail(PBH_ERR_INVALID, "NULL argument");
+#ifdef PBH_F64
+    return fail(PBH_ERR_UNSUPPORTED, "raw streaming decodes to complex64");
+#else
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    if (L->ncomp != 2) return fail(PBH_ERR_INVALID, "raw streaming needs complex samples (ncomp = 2)");
+    if (first < 0) return fail(PBH_ERR_INVALID, "first must be non-negative");
+    const int64_t hop = p->stop - p->start;
+    if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
+    if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
+    const int64_t nchunk = (total_nsample - p->N) / hop + 1;
+    // spans of all chunks up front: bounds checks, and the size of the device raw buffers
+    std::vector<DecodeSpan> spans((size_t)nchunk);
+    size_t cap = 0;
+    for (int64_t k = 0; k < nchunk; ++k) {
+        PBHCHECK(decode_span(L, first + k * hop, p->N, p->nchan, p->npol, raw_bytes, &spans[(size_t)k]));
+        cap = spans[(size_t)k].len > cap ? spans[(size_t)k].len : cap;
+    }
+    HIPCHECK(hipSetDevice(p->device));
+    const bool sm = !(p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
+                      p->N >= (1LL << 31)) && p->S > 1;
+    const size_t row = sizeof(cf) * (size_t)p->S;
+    const size_t out_bytes = row * (size_t)hop, host_out_bytes = out_bytes * (size_t)nchunk;
+
+    void* draw[2] = {nullptr, nullptr};
+    void* dout[2] = {nullptr, nullptr};
+    void *dec = nullptr, *dconj = nullptr;
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool reg_in = false, reg_out = false;
+    int rc = PBH_OK;
+    auto hipok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
+        if ((rc = dev_alloc(nullptr, &draw[b], cap + 16)) != PBH_OK) break;
+        rc = dev_alloc(nullptr, &dout[b], out_bytes);
+    }
+    if (rc == PBH_OK) rc = dev_alloc(nullptr, &dec, row * (size_t)p->N);
+    bool any_conj = false;
+    if (conj_mask)
+        for (int i = 0; i < p->S; ++i) any_conj |= conj_mask[i] != 0;
+    if (rc == PBH_OK && any_conj) {
+        rc = dev_alloc(nullptr, &dconj, (size_t)p->S);
+        if (rc == PBH_OK) hipok(xfer_h2d(dconj, conj_mask, (size_t)p->S, p->stream), "mask copy");
+    }
+    if (rc == PBH_OK) {
+        reg_in = hipHostRegister(const_cast<void*>(host_raw), raw_bytes, hipHostRegisterDefault) == hipSuccess;
+        reg_out = hipHostRegister(host_out, host_out_bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+        hipok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
+        hipok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
+        hipok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
+        for (int b = 0; b < 2; ++b) {
+            hipok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
+            hipok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
+            hipok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
+        }
+        hipok(hipEventCreate(&t0), "hipEventCreate");
+        hipok(hipEventCreate(&t1), "hipEventCreate");
+    }
+    if (rc == PBH_OK) {
+        hipok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
+        hipok(hipEventRecord(t0, s_in), "hipEventRecord");
+        hipok(hipStreamWaitEvent(s_cmp, t0, 0), "hipStreamWaitEvent");
+        IoLayout io;
+        if (sm) {
+            io.in_layout = PBH_LAYOUT_SERIES_MAJOR;
+            io.in_pitch = p->N;
+        }
+        for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
+            const int b = (int)(k & 1);
+            const DecodeSpan& sp = spans[(size_t)k];
+            char* dst = (char*)host_out + (size_t)k * out_bytes;
+            if (k >= 2) hipok(hipStreamWaitEvent(s_in, ev_cmp[b], 0), "hipStreamWaitEvent");  // raw[b] consumed
+            // (+ off % 16 keeps the parity / alignment of the file offsets on the device)
+            unsigned char* dbase = (unsigned char*)draw[b] + sp.off % 16;
+            hipok(hipMemcpyAsync(dbase, (const char*)host_raw + sp.off, sp.len, hipMemcpyHostToDevice, s_in), "hipMemcpyAsync H2D");
+            hipok(hipEventRecord(ev_in[b], s_in), "hipEventRecord");
+            hipok(hipStreamWaitEvent(s_cmp, ev_in[b], 0), "hipStreamWaitEvent");
+            if (k >= 2) hipok(hipStreamWaitEvent(s_cmp, ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
+            if (rc == PBH_OK)
+                rc = decode_launch(dbase - sp.off, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
+                                   sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, s_cmp);
+            if (rc == PBH_OK) {
+                auto steps = build_steps(p, (const cf*)dec, (cf*)dout[b], DetectTail(), io);
+                rc = run_steps(steps, s_cmp);
+            }
+            hipok(hipEventRecord(ev_cmp[b], s_cmp), "hipEventRecord");
+            hipok(hipStreamWaitEvent(s_out, ev_cmp[b], 0), "hipStreamWaitEvent");
+            hipok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, s_out), "hipMemcpyAsync D2H");
+            hipok(hipEventRecord(ev_out[b], s_out), "hipEventRecord");
+        }
+        hipok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
+        hipok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
+        hipok(hipEventRecord(t1, s_out), "hipEventRecord");
+        hipok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
+        if (rc == PBH_OK && ms_total) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, t0, t1);
+            *ms_total = ms;
+        }
+    }
+    if (reg_in) hipHostUnregister(const_cast<void*>(host_raw));
+    if (reg_out) hipHostUnregister(host_out);
+    for (int b = 0; b < 2; ++b) {
+        if (draw[b]) hipFree(draw[b]);
+        if (dout[b]) hipFree(dout[b]);
+        if (ev_in[b]) hipEventDestroy(ev_in[b]);
+        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
+        if (ev_out[b]) hipEventDestroy(ev_out[b]);
+    }
+    if (dec) hipFree(dec);
+    if (dconj) hipFree(dconj);
+    if (t0) hipEventDestroy(t0);
+    if (t1) hipEventDestroy(t1);
+    if (s_in) hipStreamDestroy(s_in);
+    if (s_cmp) hipStreamDestroy(s_cmp);
+    if (s_out) hipStreamDestroy(s_out);
+    if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
+    return rc;
+#endif
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------

@@ -233,7 +233,7 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
 
 
-def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto"):
+def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto", offset=0, n=None):
     """Overlap-save dedispersion of a long host-resident signal in chunks of ``chunk`` samples.
 
     Equals ``pb.concatenate([coherent_dedispersion(z[k*hop : k*hop + chunk], DM, ref_freq=ref)
@@ -241,11 +241,21 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     recipe for long series: SURVEY.md 5, transforms.py:59-148), but uploads chunk k+1 and downloads
     chunk k-1 while chunk k is on the GPU (double-buffered hipMemcpyAsync).  Returns the signal
     (start_time advanced by the crop start) and the HIP-event milliseconds of the whole stream.
+
+    ``z`` may also be a ``pulsarbat_amd.readers.BasebandReader`` of complex voltage data (``offset`` / ``n`` select
+    the samples): then the file's payload bytes are what crosses PCIe and every chunk is unpacked on the
+    device in front of its transforms (``pbh_dedisperse_stream_raw``) -- the same result as streaming
+    ``reader.read(offset, n)``, at a quarter of the upload for 8-bit samples.
     """
+    from ..readers import BasebandReader
+    if isinstance(z, BasebandReader):
+        return _stream_from_reader(z, DM, chunk, ref_freq, variant, offset, n)
     if not isinstance(z, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
     if isinstance(z.data, DeviceArray):
         raise TypeError("coherent_dedispersion_stream takes a host-resident signal")
+    if offset or n is not None:
+        z = z[offset:None if n is None else offset + n]
     if ref_freq is None:
         ref_freq = z.center_freq
     head = z[:chunk]
@@ -253,6 +263,38 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
     y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
     return type(z).like(z, y, **_advance(z, start)), ms
+
+
+def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n):
+    if not issubclass(reader._signal_type, BasebandSignal) or reader.intensity or not reader.complex_data:
+        raise TypeError("streaming from a reader needs complex voltage data in a BasebandSignal type")
+    n = len(reader) - offset if n is None else n
+    if offset < 0 or n < 0 or offset + n > len(reader):
+        raise EOFError("Cannot read beyond end of stream")
+    # a zero-stride stand-in carries the metadata the plan is built from
+    blank = np.broadcast_to(np.complex64(0), (chunk,) + reader.sample_shape)
+    head = reader._signal_type(blank, sample_rate=reader.sample_rate, start_time=reader.time_at(offset),
+                               **reader._signal_kwargs)
+    if ref_freq is None:
+        ref_freq = head.center_freq
+    start, stop = _crop_bounds(head, DM, ref_freq)
+    plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
+    shape1, strides, elem0 = reader._axes()
+    if tuple(shape1) != (plan.nchan, plan.npol):
+        # unit axes dropped by squeezing: the remaining one is the channel axis
+        keep = [i for i in (0, 1) if shape1[i] != 1]
+        if len(keep) != 1 or shape1[keep[0]] != plan.nchan or plan.npol != 1:
+            raise ValueError(f"reader samples {tuple(shape1)} do not map onto ({plan.nchan}, {plan.npol}) series")
+        strides = (strides[keep[0]], 0)
+    buf, first = reader._raw.fetch(offset, n)
+    lay = reader._raw.layout()
+    lay.update(elem0=elem0, stride_c=strides[0], stride_p=strides[1])
+    mask = reader._conj_mask(shape1)
+    if mask is not None:
+        mask = np.asarray(mask).reshape(plan.nchan, plan.npol)
+    y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask)
+    y = y.reshape((len(y),) + reader.sample_shape)
+    return type(head).like(head, y, **_advance(head, start)), ms
 
 
 def incoherent_dedispersion(z, DM, /, *, ref_freq=None):

@@ -287,3 +287,58 @@ class TestDeviceDecode:
             _hip.decode(raw, dict(lay, stride_t=3), 0, 150, 2, 1)   # a block's samples overrun into the next block
         with pytest.raises(errors):
             _hip.decode(raw, dict(lay, nbits=4), 0, 10, 2, 1)
+
+
+# ---- streaming straight from the payload bytes (pbh_dedisperse_stream_raw) -----------------------------------
+@pytest.mark.gpu
+class TestRawStream:
+    @pytest.mark.parametrize("chunk,dm", [(1 << 13, 0.5), (1 << 15, 0.5), (1 << 14, 1.0)])
+    def test_guppi_reader_stream(self, chunk, dm):
+        """Equals the overlap-save stream over the decoded samples (one reference call per chunk)."""
+        r = pbr.GUPPIRawReader(GUPPI)
+        x = ro.guppi_samples(GUPPI).transpose(0, 2, 1)
+        y, ms = pb.coherent_dedispersion_stream(r, pb.DM(dm), chunk=chunk)
+        first, start, stop = orc.coherent_dedispersion(x[:chunk], dm, 3.125e6, 344.1875e6)
+        hop = stop - start
+        nchunk = (len(x) - chunk) // hop + 1
+        want = np.concatenate([orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, 3.125e6, 344.1875e6)[0]
+                               for k in range(nchunk)], axis=0)
+        assert y.shape == want.shape and ms > 0 and type(y) is pb.DualPolarizationSignal
+        assert np.linalg.norm(np.asarray(y) - want) / np.linalg.norm(want) < 1e-5
+        assert abs((y.start_time - r.start_time).to_value(u.s) - start / 3.125e6) < 1e-12
+        if chunk > len(x) - 1500:
+            return
+        # a window of the file
+        y2, _ = pb.coherent_dedispersion_stream(r, pb.DM(dm), chunk=chunk, offset=1000, n=len(x) - 1500)
+        z = r.read(1000, len(x) - 1500)
+        y3, _ = pb.coherent_dedispersion_stream(type(z).like(z, np.asarray(z)), pb.DM(dm), chunk=chunk)
+        assert y2.shape == y3.shape and y2.start_time.isclose(y3.start_time)
+        assert np.linalg.norm(np.asarray(y2) - np.asarray(y3)) / np.linalg.norm(np.asarray(y3)) < 2e-6
+
+    def test_synthetic_blocks(self):
+        """Headered blocks, offset-binary samples, a conjugation mask and a scale: equals the stream over
+        the numpy-decoded array."""
+        from pulsarbat_amd import _hip
+        rng = np.random.default_rng(9)
+        nchan, npol, blk_t, nblk, hdr = 4, 2, 3000, 90, 64
+        pay = blk_t * nchan * npol * 2
+        stride = hdr + pay
+        raw = rng.integers(0, 256, nblk * stride, dtype=np.uint8)
+        lay = dict(nbits=8, ncomp=2, code=1, blk_samples=blk_t, blk_stride=stride, hdr_bytes=hdr, elem0=0,
+                   stride_t=npol, stride_c=blk_t * npol, stride_p=1)
+        total, first, chunk = 250000, 777, 1 << 16
+        conj = np.array([[0, 1], [0, 0], [1, 1], [1, 0]], bool)
+        x = ro.unpack_general(raw, lay, first, total, nchan, npol) * np.float32(1 / 64)
+        x = np.where(conj[None], x.conj(), x)
+        sr, fc, dm = 1e6, 1e9, 30.0
+        z = pb.DualPolarizationSignal(x, sample_rate=sr * u.Hz, center_freq=fc * u.Hz, pol_type="linear")
+        ya, _ = pb.coherent_dedispersion_stream(z, pb.DM(dm), chunk=chunk)
+        from pulsarbat_amd.transforms.dedispersion import _crop_bounds, _plan_for
+        head = z[:chunk]
+        plan, _ = _plan_for(head, pb.DM(dm), head.center_freq, _crop_bounds(head, pb.DM(dm), head.center_freq))
+        yb, ms = plan.dedisperse_stream_raw(raw, lay, total, first=first, conj=conj, scale=1 / 64)
+        assert yb.shape == ya.shape and ms > 0
+        assert np.linalg.norm(yb - np.asarray(ya)) / np.linalg.norm(np.asarray(ya)) < 2e-6
+        with pytest.raises((ValueError, _hip.HipError)):
+            plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk + 1)      # one sample beyond the buffer
+        plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk)
