@@ -302,65 +302,85 @@ struct DecodeParams {
     int64_t pitch;
 };
 
-__device__ __forceinline__ float decode_component(const unsigned char* pay, int64_t ci, int nbits, int code) {
-    if (nbits == 8) {
-        const int v = pay[ci];
-        return code ? (float)(v - 128) : (float)(signed char)v;
-    }
-    const int v = (pay[ci >> 2] >> (2 * (int)(ci & 3))) & 3;
-    const float mag = (v == 0 || v == 3) ? 3.3359f : 1.0f;   // optimal 4-level thresholds (VDIF / Mark 5 convention)
-    return (v & 2) ? mag : -mag;
-}
-
 // One workgroup unpacks a tile of 4096 elements, TS = 2^ls series by TT = 4096/TS time samples (TS = the series
 // count rounded up to a power of two, at most 64, so that no lanes idle when there are few series), through LDS:
 // consecutive lanes read along the payload's fastest axis and write along the output's.
 constexpr int kDecodeTile = 4096;
 constexpr int kDecodeLds = 5120;   // TS >= 4 rows are padded by one element
 
-template <int NC>
+// FAST: blocks at least as long as a tile's time extent (one wrap at most), npol a power of two and, for 8-bit
+// complex data, elements at even addresses (one 16-bit load) -- the loop body is then free of branches and all
+// 16 loads of a thread are in flight together; the general form keeps the divisions and byte loads.
+template <int NC, int NBITS, bool FAST>
 __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
     __shared__ float lds[NC][kDecodeLds];
+    constexpr int NJ = kDecodeTile / 256;
+    constexpr bool PAIR = FAST && NC == 2 && NBITS == 8;
     const int ls = q.ls, TS = 1 << ls, lt = 12 - ls, TT = 1 << lt;
     const int pitch = TS < 4 ? TS : TS + 1;
     const int64_t t0 = (int64_t)blockIdx.x * TT;
     const int s0 = blockIdx.y * TS, S = q.nchan * q.npol;
     const int64_t g0 = q.first + t0, blk0 = g0 / q.blk_t, w0 = g0 - blk0 * q.blk_t;   // uniform: once per workgroup
-    const bool one_wrap = q.blk_t >= TT;
+    // indices of lanes beyond the data are clamped to the last sample / series (addresses the host has
+    // bounds-checked) instead of branching around the load
+    const int64_t tlim = q.n - 1 - t0;   // >= 0: the grid covers [0, n)
+    unsigned raw[NC][NJ];
+    int shift[NC][NJ];
 #pragma unroll
-    for (int j = 0; j < kDecodeTile / 256; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int idx = threadIdx.x + 256 * j;
-        const int tt = q.lanes_t ? (idx & (TT - 1)) : (idx >> ls), ss = q.lanes_t ? (idx >> lt) : (idx & (TS - 1));
-        const int s = s0 + ss;
-        if (t0 + tt < q.n && s < S) {
-            int64_t w = w0 + tt, blk = blk0;
-            if (w >= q.blk_t) {
-                if (one_wrap) {
-                    w -= q.blk_t;
-                    ++blk;
-                } else {
-                    const int64_t d = w / q.blk_t;
-                    blk += d;
-                    w -= d * q.blk_t;
-                }
-            }
-            const int c = q.npol_shift >= 0 ? (s >> q.npol_shift) : s / q.npol, p = s - c * q.npol;
-            const int64_t e = q.e0 + w * q.st_t + c * q.st_c + p * q.st_p;
-            const unsigned char* pay = q.raw + blk * q.blk_stride + q.hdr;
-            if (NC == 2 && q.pair16) {   // 8-bit complex at an even address: one 16-bit load
-                const int v = *reinterpret_cast<const unsigned short*>(pay + 2 * e);
-                const int re = v & 0xFF, im = v >> 8;
-                lds[0][tt * pitch + ss] = q.code ? (float)(re - 128) : (float)(signed char)re;
-                lds[NC - 1][tt * pitch + ss] = q.code ? (float)(im - 128) : (float)(signed char)im;
-            } else {
+        int tt = q.lanes_t ? (idx & (TT - 1)) : (idx >> ls), ss = q.lanes_t ? (idx >> lt) : (idx & (TS - 1));
+        tt = tt > tlim ? (int)tlim : tt;
+        const int s = s0 + ss < S ? s0 + ss : S - 1;
+        int64_t w = w0 + tt, blk = blk0;
+        int c;
+        if (FAST) {
+            const bool wrap = w >= q.blk_t;
+            w -= wrap ? q.blk_t : 0;
+            blk += wrap ? 1 : 0;
+            c = s >> q.npol_shift;
+        } else {
+            const int64_t d = w / q.blk_t;
+            blk += d;
+            w -= d * q.blk_t;
+            c = s / q.npol;
+        }
+        const int p = s - c * q.npol;
+        const int64_t e = q.e0 + w * q.st_t + c * q.st_c + p * q.st_p;
+        const unsigned char* pay = q.raw + blk * q.blk_stride + q.hdr;
+        if (PAIR) {
+            raw[0][j] = *reinterpret_cast<const unsigned short*>(pay + 2 * e);
+        } else {
 #pragma unroll
-                for (int k = 0; k < NC; ++k) lds[k][tt * pitch + ss] = decode_component(pay, e * NC + k, q.nbits, q.code);
+            for (int k = 0; k < NC; ++k) {
+                const int64_t ci = e * NC + k;
+                raw[k][j] = NBITS == 8 ? pay[ci] : pay[ci >> 2];
+                shift[k][j] = 2 * (int)(ci & 3);
             }
         }
     }
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kDecodeTile / 256; ++j) {
+    for (int j = 0; j < NJ; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        const int tt = q.lanes_t ? (idx & (TT - 1)) : (idx >> ls), ss = q.lanes_t ? (idx >> lt) : (idx & (TS - 1));
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            float val;
+            if (NBITS == 8) {
+                const int v = PAIR ? (int)((raw[0][j] >> (8 * k)) & 0xFF) : (int)raw[k][j];
+                val = q.code ? (float)(v - 128) : (float)(signed char)v;
+            } else {
+                const int c2 = (raw[k][j] >> shift[k][j]) & 3;
+                const float mag = (c2 == 0 || c2 == 3) ? 3.3359f : 1.0f;   // optimal 4-level thresholds (VDIF / Mark 5)
+                val = (c2 & 2) ? mag : -mag;
+            }
+            lds[k][tt * pitch + ss] = val;   // (clamped lanes fill their own, unused, slot)
+        }
+    }
+    __syncthreads();
+    const bool has_conj = q.conj != nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         const int idx = threadIdx.x + 256 * j;
         const int tt = q.series_major ? (idx & (TT - 1)) : (idx >> ls), ss = q.series_major ? (idx >> lt) : (idx & (TS - 1));
         const int64_t t = t0 + tt;
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
             const float re = lds[0][tt * pitch + ss] * q.scale;
             if (NC == 2) {
                 float im = lds[NC - 1][tt * pitch + ss] * q.scale;
-                if (q.conj && q.conj[s]) im = -im;
+                if (has_conj && q.conj[s]) im = -im;
                 reinterpret_cast<float2*>(q.out)[o] = make_float2(re, im);
             } else {
                 q.out[o] = re;

@@ -949,10 +949,19 @@ static int decode_launch(const unsigned char* draw, const pbh_raw_layout_t* L, i
                ((uintptr_t)draw) % 2 == 0;
     const int TS = 1 << q.ls, TT = kDecodeTile / TS;
     const dim3 grid((unsigned)((nsample + TT - 1) / TT), (unsigned)((S + TS - 1) / TS));
-    if (L->ncomp == 2)
-        hipLaunchKernelGGL(k_decode<2>, grid, dim3(256), 0, st, q);
-    else
-        hipLaunchKernelGGL(k_decode<1>, grid, dim3(256), 0, st, q);
+    const bool fast = L->blk_samples >= TT && q.npol_shift >= 0 && (L->ncomp == 1 || L->nbits != 8 || q.pair16);
+#define LAUNCH(NC, NB)                                                                       \
+    do {                                                                                      \
+        if (fast)                                                                             \
+            hipLaunchKernelGGL((k_decode<NC, NB, true>), grid, dim3(256), 0, st, q);          \
+        else                                                                                  \
+            hipLaunchKernelGGL((k_decode<NC, NB, false>), grid, dim3(256), 0, st, q);         \
+    } while (0)
+    if (L->ncomp == 2 && L->nbits == 8) LAUNCH(2, 8);
+    else if (L->ncomp == 2) LAUNCH(2, 2);
+    else if (L->nbits == 8) LAUNCH(1, 8);
+    else LAUNCH(1, 2);
+#undef LAUNCH
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
