@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* 
 // (t, chan, pol) sits at element index e0 + t*st_t + chan*st_c + pol*st_p (strides may be negative: channel flip),
 // an element being 1 (real) or 2 (complex, re then im) components of `nbits` bits, low bits first in each byte.
 struct DecodeParams {
-    const unsigned char* raw;
-    int64_t first;       // first wanted time sample, in valid samples from the start of `raw`
+    const unsigned char* raw;   // device copy of bytes [skip, ...) of the payload stream
+    int64_t skip;        // stream offset of raw[0]: only the blocks that are needed are on the device
+    int64_t first;       // first wanted time sample, in valid samples from the start of the stream
     int64_t blk_t;       // time samples per block
     int64_t blk_stride;  // bytes from one block to the next
     int64_t hdr;         // bytes from the start of a block to its payload
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
         }
         const int p = s - c * q.npol;
         const int64_t e = q.e0 + w * q.st_t + c * q.st_c + p * q.st_p;
-        const unsigned char* pay = q.raw + blk * q.blk_stride + q.hdr;
+        const unsigned char* pay = q.raw + (blk * q.blk_stride + q.hdr - q.skip);
         if (PAIR) {
             raw[0][j] = *reinterpret_cast<const unsigned short*>(pay + 2 * e);
         } else {

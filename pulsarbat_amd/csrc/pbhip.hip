@@ -913,12 +913,13 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
     return PBH_OK;
 }
 
-// draw: device address that byte 0 of the raw buffer would have (only offsets inside the checked span are formed)
-static int decode_launch(const unsigned char* draw, const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan,
+// draw: device copy of the raw stream from byte `skip` on (only offsets inside the checked span are formed)
+static int decode_launch(const unsigned char* draw, int64_t skip, const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan,
                          int npol, const unsigned char* dconj, float scale, void* out_dev, int out_layout,
                          int64_t out_pitch, hipStream_t st) {
     DecodeParams q;
     q.raw = draw;
+    q.skip = skip;
     q.first = first;
     q.blk_t = L->blk_samples;
     q.blk_stride = L->blk_stride;
@@ -946,7 +947,7 @@ static int decode_launch(const unsigned char* draw, const pbh_raw_layout_t* L, i
     while (q.ls < 6 && (1 << q.ls) < S) ++q.ls;
     q.npol_shift = is_pow2(npol) ? ilog2(npol) : -1;
     q.pair16 = L->nbits == 8 && L->ncomp == 2 && L->blk_stride % 2 == 0 && L->hdr_bytes % 2 == 0 &&
-               ((uintptr_t)draw) % 2 == 0;
+               ((uintptr_t)draw) % 2 == 0 && skip % 2 == 0;
     const int TS = 1 << q.ls, TT = kDecodeTile / TS;
     const dim3 grid((unsigned)((nsample + TT - 1) / TT), (unsigned)((S + TS - 1) / TS));
     const bool fast = L->blk_samples >= TT && q.npol_shift >= 0 && (L->ncomp == 1 || L->nbits != 8 || q.pair16);
@@ -985,6 +986,7 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
         if (sconj) hipFree(sconj);
     };
     const unsigned char* draw = (const unsigned char*)raw;
+    int64_t skip = 0;
     int rc = PBH_OK;
     if (raw_loc == PBH_HOST) {   // only the blocks that are read travel
         if ((rc = dev_alloc(nullptr, &sraw, sp.len)) != PBH_OK) return rc;
@@ -992,7 +994,8 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
             cleanup();
             return fail(PBH_ERR_HIP, "pbh_decode: host -> device copy failed");
         }
-        draw = (const unsigned char*)sraw - sp.off;
+        draw = (const unsigned char*)sraw;
+        skip = (int64_t)sp.off;
     }
     bool any_conj = false;
     if (conj_mask && L->ncomp == 2)
@@ -1007,7 +1010,7 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
             return fail(PBH_ERR_HIP, "pbh_decode: mask copy failed");
         }
     }
-    rc = decode_launch(draw, L, first, nsample, nchan, npol, (const unsigned char*)sconj, scale, out_dev, out_layout,
+    rc = decode_launch(draw, skip, L, first, nsample, nchan, npol, (const unsigned char*)sconj, scale, out_dev, out_layout,
                        out_pitch, st);
     hipError_t e = hipSuccess;
     if (sraw || sconj) e = hipStreamSynchronize(st);   // staging is freed below: the kernel must be done with it
@@ -2292,7 +2295,7 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
             hipok(hipStreamWaitEvent(s_cmp, ev_in[b], 0), "hipStreamWaitEvent");
             if (k >= 2) hipok(hipStreamWaitEvent(s_cmp, ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
             if (rc == PBH_OK)
-                rc = decode_launch(dbase - sp.off, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
+                rc = decode_launch(dbase, (int64_t)sp.off, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
                                    sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, s_cmp);
             if (rc == PBH_OK) {
                 auto steps = build_steps(p, (const cf*)dec, (cf*)dout[b], DetectTail(), io);
