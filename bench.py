@@ -133,9 +133,16 @@ def main():
             log(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
             sys.exit(2)
     distributed = world > 1 or "RANK" in os.environ  # under torchrun: exercise RCCL even with one rank
+    # PBH_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("PBH_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         mark("process group ready")
 
     from pulsarbat_amd import _hip
