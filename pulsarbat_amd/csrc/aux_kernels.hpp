@@ -485,14 +485,17 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
     }
 }
 
+#endif  // !PBH_F64
+
 // ---- layout passes with the radix-P stage of a long column transform folded in ----------------------------
 // (see k_radix_p).  A workgroup handles the same TN time samples of all P chunks (N/P apart): forward it
 // reads P interleaved tiles, does the P-point DFT + twiddle across them in registers and writes P planar
 // tiles; inverse it reads P planar tiles, undoes the stage and writes P interleaved tiles, cropped.  Long
 // blocks are back to five passes.  E elements per chunk tile, chosen so a thread holds <= 32 float4.
+constexpr int radix_tile_e(int P) { return P <= 4 ? 4096 : (P <= 8 ? 2048 : 1024); }   // (the float32 inverse kernel at P = 7 spills 390 B/lane; 1024-element tiles are slower still: 54 vs 59 Gsamples/s)
 template <int P>
 struct RadixTile {
-    static constexpr int E = P <= 4 ? 4096 : (P <= 8 ? 2048 : 1024);
+    static constexpr int E = radix_tile_e(P);
 };
 template <int P>
 __device__ __forceinline__ void radix_twiddles(cf (&tw)[P], int64_t b, int N1, int dir) {
@@ -508,21 +511,26 @@ __device__ __forceinline__ void radix_twiddles(cf (&tw)[P], int64_t b, int N1, i
     }
 }
 
+// (both precisions: a thread moves 16-byte vectors, VE = 2 complex64 or 1 complex128 elements, and a chunk tile
+//  is the same 8 * RadixTile<P>::E bytes)
 template <int S, int P>
 __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, cf* __restrict__ out, int64_t chunk,
                                                      int64_t plane, int N2, int N1, int64_t nvalid) {
-    constexpr int E = RadixTile<P>::E, TN = E / S, LD = TN + 1, NV = E / 2 / 256;
+    constexpr int VE = 16 / (int)sizeof(cf);
+    constexpr int E = RadixTile<P>::E * 8 / (int)sizeof(cf), TN = E / S, LD = TN + 1, NV = E / VE / 256;
+    typedef real vecr __attribute__((ext_vector_type(2 * VE)));
+    static_assert(S % VE == 0 && TN % VE == 0 && NV >= 1, "k_deint_radix: tile shape");
     __shared__ cf lds[S * LD];
     const int64_t n0 = (int64_t)blockIdx.x * TN;
-    float4 v[P][NV];
+    vecr v[P][NV];
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-        const float4* src = reinterpret_cast<const float4*>(in + ((int64_t)a * chunk + n0) * S);
+        const vecr* src = reinterpret_cast<const vecr*>(in + ((int64_t)a * chunk + n0) * S);
         const int64_t t0 = (int64_t)a * chunk + n0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int e = 2 * (threadIdx.x + 256 * j);
-            v[a][j] = (t0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : make_float4(0, 0, 0, 0);   // zero padding
+            const int e = VE * (threadIdx.x + 256 * j);
+            v[a][j] = (t0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : (vecr)(real)0;   // zero padding
         }
     }
     cf tw[P];
@@ -530,17 +538,17 @@ __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, 
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < VE; ++h) {
             cf x[P];
 #pragma unroll
-            for (int a = 0; a < P; ++a) x[a] = h ? make_cf(v[a][j].z, v[a][j].w) : make_cf(v[a][j].x, v[a][j].y);
+            for (int a = 0; a < P; ++a) x[a] = make_cf(v[a][j][2 * h], v[a][j][2 * h + 1]);
             Dft<P, -1>::run(x);
 #pragma unroll
             for (int c = 1; c < P; ++c) x[c] = cmul(x[c], tw[c]);
 #pragma unroll
             for (int c = 0; c < P; ++c) {
-                if (h) { v[c][j].z = x[c].x; v[c][j].w = x[c].y; }
-                else { v[c][j].x = x[c].x; v[c][j].y = x[c].y; }
+                v[c][j][2 * h] = x[c].x;
+                v[c][j][2 * h + 1] = x[c].y;
             }
         }
     }
@@ -548,18 +556,24 @@ __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, 
     for (int c = 0; c < P; ++c) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int e = 2 * (threadIdx.x + 256 * j);
+            const int e = VE * (threadIdx.x + 256 * j);
             const int n = e / S, s = e % S;
-            lds[s * LD + n] = make_cf(v[c][j].x, v[c][j].y);
-            lds[(s + 1) * LD + n] = make_cf(v[c][j].z, v[c][j].w);
+#pragma unroll
+            for (int h = 0; h < VE; ++h) lds[(s + h) * LD + n] = make_cf(v[c][j][2 * h], v[c][j][2 * h + 1]);
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int pidx = threadIdx.x + 256 * j;
-            const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
-            const cf x0 = lds[s * LD + n], x1 = lds[s * LD + n + 1];
-            *reinterpret_cast<float4*>(out + (int64_t)s * plane + (int64_t)c * chunk + n0 + n) = make_float4(x0.x, x0.y, x1.x, x1.y);
+            const int s = pidx / (TN / VE), n = VE * (pidx % (TN / VE));
+            vecr o;
+#pragma unroll
+            for (int h = 0; h < VE; ++h) {
+                const cf t = lds[s * LD + n + h];
+                o[2 * h] = t.x;
+                o[2 * h + 1] = t.y;
+            }
+            *reinterpret_cast<vecr*>(out + (int64_t)s * plane + (int64_t)c * chunk + n0 + n) = o;
         }
         __syncthreads();
     }
@@ -568,7 +582,9 @@ __global__ __launch_bounds__(256) void k_deint_radix(const cf* __restrict__ in, 
 template <int S, int P>
 __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, cf* __restrict__ out, int64_t chunk,
                                                      int64_t plane, int N2, int N1, int64_t start, int64_t stop) {
-    constexpr int E = RadixTile<P>::E, TN = E / S, LD = TN + 1, NV = E / 2 / 256;
+    constexpr int VE = 16 / (int)sizeof(cf);
+    constexpr int E = RadixTile<P>::E * 8 / (int)sizeof(cf), TN = E / S, LD = TN + 1, NV = E / VE / 256;
+    typedef real vecr __attribute__((ext_vector_type(2 * VE)));
     __shared__ cf lds[S * LD];
     const int64_t n0 = (int64_t)blockIdx.x * TN;
     // nothing to do when none of the P tiles reaches the kept range
@@ -576,24 +592,28 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
 #pragma unroll
     for (int a = 0; a < P; ++a) any |= ((int64_t)a * chunk + n0 < stop) && ((int64_t)a * chunk + n0 + TN > start);
     if (!any) return;
-    float4 v[P][NV];
+    vecr v[P][NV];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int pidx = threadIdx.x + 256 * j;
-            const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
-            const float4 t = *reinterpret_cast<const float4*>(in + (int64_t)s * plane + (int64_t)c * chunk + n0 + n);
-            lds[s * LD + n] = make_cf(t.x, t.y);
-            lds[s * LD + n + 1] = make_cf(t.z, t.w);
+            const int s = pidx / (TN / VE), n = VE * (pidx % (TN / VE));
+            const vecr t = *reinterpret_cast<const vecr*>(in + (int64_t)s * plane + (int64_t)c * chunk + n0 + n);
+#pragma unroll
+            for (int h = 0; h < VE; ++h) lds[s * LD + n + h] = make_cf(t[2 * h], t[2 * h + 1]);
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int e = 2 * (threadIdx.x + 256 * j);
+            const int e = VE * (threadIdx.x + 256 * j);
             const int n = e / S, s = e % S;
-            const cf x0 = lds[s * LD + n], x1 = lds[(s + 1) * LD + n];
-            v[c][j] = make_float4(x0.x, x0.y, x1.x, x1.y);
+#pragma unroll
+            for (int h = 0; h < VE; ++h) {
+                const cf t = lds[(s + h) * LD + n];
+                v[c][j][2 * h] = t.x;
+                v[c][j][2 * h + 1] = t.y;
+            }
         }
         __syncthreads();
     }
@@ -602,17 +622,17 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < VE; ++h) {
             cf x[P];
 #pragma unroll
-            for (int c = 0; c < P; ++c) x[c] = h ? make_cf(v[c][j].z, v[c][j].w) : make_cf(v[c][j].x, v[c][j].y);
+            for (int c = 0; c < P; ++c) x[c] = make_cf(v[c][j][2 * h], v[c][j][2 * h + 1]);
 #pragma unroll
             for (int c = 1; c < P; ++c) x[c] = cmul(x[c], tw[c]);
             Dft<P, +1>::run(x);
 #pragma unroll
             for (int a = 0; a < P; ++a) {
-                if (h) { v[a][j].z = x[a].x; v[a][j].w = x[a].y; }
-                else { v[a][j].x = x[a].x; v[a][j].y = x[a].y; }
+                v[a][j][2 * h] = x[a].x;
+                v[a][j][2 * h + 1] = x[a].y;
             }
         }
     }
@@ -621,15 +641,13 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
         const int64_t t0 = (int64_t)a * chunk + n0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int e = 2 * (threadIdx.x + 256 * j);
+            const int e = VE * (threadIdx.x + 256 * j);
             const int64_t t = t0 + e / S;
             if (t >= start && t < stop)
-                *reinterpret_cast<float4*>(out + (t - start) * S + (e % S)) = v[a][j];
+                *reinterpret_cast<vecr*>(out + (t - start) * S + (e % S)) = v[a][j];
         }
     }
 }
-
-#endif  // !PBH_F64
 
 // ---- detection (pulsarbat/core.py:766-774, 930-966), optional time scrunch -----------------------------
 // in: (n, nchan, npol) c64.  One thread per (output row, chan); sums nscrunch input rows in float32.

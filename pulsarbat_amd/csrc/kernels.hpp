@@ -353,6 +353,8 @@ struct RowParams {
     int N1, npol;
     int perm_w;        // chirp row order (see ChirpParams::perm_w); 8 selects k_row2
     unsigned* counter; // SP = 2: dynamic tile hand-out (zeroed before the launch); null = static stride
+    int cP = 1;        // the chirp rows are stored in the order of a column transform split cP x (N1/cP) while the data rows
+                       // are in natural k1 order (one row per tile only): row k1 of the chirp is at (k1 % cP)*(N1/cP) + k1/cP
 #ifdef PBH_DIAGNOSTIC
     unsigned long long* dbg;  // ABL = 4: [block][iteration < 64][8] s_memtime stamps
 #endif
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
             if (tid == 0 && p.counter) fetched = 2 * gridDim.x + atomicAdd(p.counter, 1u);
         }
         const int64_t srs = r0 / p.N1;
-        const int k1 = (int)(r0 - srs * p.N1);
+        const int k1d = (int)(r0 - srs * p.N1);
+        const int k1 = p.cP > 1 ? (k1d % p.cP) * (p.N1 / p.cP) + k1d / p.cP : k1d;
         const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M,
                                     (uint32_t)(FR * (int64_t)M * sizeof(cf)));
         if constexpr (PF) {
@@ -592,6 +595,7 @@ struct RowpParams {
     int nchan, N1, npol;
     real scale;          // 1/N
     unsigned* counter;   // pair hand-out (zeroed before the launch); null = static stride
+    int cP = 1;          // phase rows stored in split order cP x (N1/cP), data rows in natural order (RowParams::cP)
 };
 
 template <int M, int R>
@@ -633,7 +637,12 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
     while (true) {
         launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
         if (pol == 0) {   // wave-uniform: a new pair -- its phase row, and the index of the pair after next
-            const rsrc_t rp = make_rsrc(p.phase + (int64_t)u * M, (uint32_t)(M * sizeof(float)));
+            uint32_t up = u;
+            if (p.cP > 1) {
+                const uint32_t ch = u / (uint32_t)p.N1, k1d = u - ch * (uint32_t)p.N1;
+                up = ch * (uint32_t)p.N1 + (k1d % (uint32_t)p.cP) * (uint32_t)(p.N1 / p.cP) + k1d / (uint32_t)p.cP;
+            }
+            const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * M, (uint32_t)(M * sizeof(float)));
 #pragma unroll
             for (int i = 0; i < R; ++i)
                 ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));

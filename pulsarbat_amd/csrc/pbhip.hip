@@ -474,23 +474,17 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
 
 // Layout passes with the radix-P stage folded in (float32, 2 <= S <= 128 a power of two, tiles of >= 16 samples).
 static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
-#ifdef PBH_F64
-    (void)S; (void)P; (void)N; (void)N2;
-    return false;
-#else
     static const bool on = [] { const char* e = getenv("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
     if (!on || S < 2 || S > 128 || (S & (S - 1)) != 0) return false;
     if (P != 2 && P != 3 && P != 4 && P != 5 && P != 7 && P != 8 && P != 16) return false;
-    const int E = P <= 4 ? 4096 : (P <= 8 ? 2048 : 1024), TN = E / S;
-    return TN >= 16 && (N / P) % TN == 0 && N2 % TN == 0;
-#endif
+    const int E = radix_tile_e(P) * 8 / (int)sizeof(cf), TN = E / S;   // RadixTile<P>
+    return TN >= 128 / (int)sizeof(cf) && (N / P) % TN == 0 && N2 % TN == 0;   // planar rows of whole 128-byte lines
 }
-#ifndef PBH_F64
 template <int S>
 static int launch_deint_radix_s(int P, const cf* in, cf* work, int64_t N, int N2, int N1, int64_t nvalid, hipStream_t st) {
     const int64_t chunk = N / P;
     switch (P) {
-#define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1, nvalid); break;
+#define X(pp) case pp: hipLaunchKernelGGL((k_deint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E * 8 / (int)sizeof(cf) / S))), dim3(256), 0, st, in, work, chunk, N, N2, N1, nvalid); break;
         X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
     }
@@ -502,35 +496,30 @@ static int launch_reint_radix_s(int P, const cf* work, cf* out, int64_t N, int N
                                 hipStream_t st) {
     const int64_t chunk = N / P;
     switch (P) {
-#define X(pp) case pp: hipLaunchKernelGGL((k_reint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E / S))), dim3(256), 0, st, work, out, chunk, N, N2, N1, start, stop); break;
+#define X(pp) case pp: hipLaunchKernelGGL((k_reint_radix<S, pp>), dim3((unsigned)(chunk / (RadixTile<pp>::E * 8 / (int)sizeof(cf) / S))), dim3(256), 0, st, work, out, chunk, N, N2, N1, start, stop); break;
         X(2) X(3) X(4) X(5) X(7) X(8) X(16)
 #undef X
     }
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
-#endif
 static int launch_deint_radix(int S, int P, const cf* in, cf* work, int64_t N, int N2, int N1, int64_t nvalid,
                               hipStream_t st) {
-#ifndef PBH_F64
     switch (S) {
 #define X(s) case s: return launch_deint_radix_s<s>(P, in, work, N, N2, N1, nvalid, st);
         X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
     }
-#endif
     return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
 }
 static int launch_reint_radix(int S, int P, const cf* work, cf* out, int64_t N, int N2, int N1, int64_t start,
                               int64_t stop, hipStream_t st) {
     if (stop <= start) return PBH_OK;
-#ifndef PBH_F64
     switch (S) {
 #define X(s) case s: return launch_reint_radix_s<s>(P, work, out, N, N2, N1, start, stop, st);
         X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
     }
-#endif
     return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
 }
 
@@ -625,10 +614,17 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
     if (variant == PBH_VARIANT_PLANAR5 || in_sm || out_sm) {
         const int64_t N = p->N, start = p->start, stop = p->stop;
-        const bool fuse_radix = p->P > 1 && !in_sm && !out_sm && radix_layout_ok(S, p->P, N, N2);
+        // A radix-2 split pays only while its stage rides in the layout passes.  Series-major arrays and the detect
+        // tail have no such pass on one side or both: they run the unsplit column passes (64-byte pieces) and the
+        // row pass finds its chirp row through the split order the chirp was stored in.
+        const bool unsplit = p->P == 2 && (in_sm || out_sm || tail.out) && N2 == kTilePoints && N1 <= kTilePoints &&
+                             N2 % (kTilePoints / N1) == 0;
+        const int P = unsplit ? 1 : p->P, Q = N1 / P;
+        const int chirp_split = unsplit ? p->P : 1;
+        const bool fuse_radix = P > 1 && !in_sm && !out_sm && radix_layout_ok(S, P, N, N2);
         const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
         if (fuse_radix) {
-            const int Pf = p->P;
+            const int Pf = P;
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
                 return launch_deint_radix(S, Pf, in, work, N, N2, N1, nvalid, st);
             }});
@@ -637,14 +633,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 return launch_deinterleave(in, work, N, S, nvalid, st);
             }});
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
-        const int P = p->P, Q = N1 / P;
         // (very short column transforms, Q < 64, leave the persistent kernel no butterflies to hide its memory
         //  traffic behind -- and its inverse form spills there: one-tile workgroups are as fast or faster)
         const bool colp = P > 1 || in_sm || out_sm ||
                           (colp_mode() != 0 && Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
-        if (in_sm && p->P == 1) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
+        if (in_sm && P == 1) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
             cp1.ld = in;
             cp1.ld_plane = io.in_pitch;
         }
@@ -664,9 +659,11 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
                      reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
+        rp.cP = chirp_split;
 #ifndef PBH_F64
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
+            rpp.cP = chirp_split;
             steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(rpp, st); }});
         } else
 #endif
@@ -674,7 +671,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         // rows outside [start, stop) are never read by k_reinterleave: skip their stores
         ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
         ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
-        if (out_sm && !tail.out && p->P == 1) {   // pass 3 writes the caller's series-major output directly, cropped
+        if (out_sm && !tail.out && P == 1) {   // pass 3 writes the caller's series-major output directly, cropped
             cp3.ld = work;
             cp3.ld_plane = N;
             cp3.data = out;
@@ -1269,9 +1266,11 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
             const int v = atoi(e);
             if (v >= PBH_R && (v & (v - 1)) == 0 && v <= kTilePoints) qmax = v;
         }
-        // worth it from 32-byte pieces down (N1 >= 4 qmax): at N1 = 2 qmax the two extra passes cost more than
-        // the 64-byte pieces do (complex64 2^25 x 16 series: 11.3 ms split vs 9.5 ms unsplit; complex128 2^24: 12.2 vs 9.8)
-        const int pmin = getenv("PBH_QMAX") ? 2 : 4;
+        // with stand-alone radix passes the split is worth it from 32-byte pieces down (N1 >= 4 qmax): at N1 = 2 qmax
+        // the two extra passes cost more than the 64-byte pieces do (complex64 2^25 x 16 series: 11.3 ms split vs
+        // 9.5 ms unsplit; complex128 2^24: 12.2 vs 9.8).  Folded into the layout passes the radix-2 stage is free:
+        // 2^25 x 16: 9.53 -> 8.57 ms (callers without layout passes run such plans unsplit, build_steps)
+        const int pmin = (getenv("PBH_QMAX") || radix_layout_ok(p->S, 2, nsample, p->N2)) ? 2 : 4;
         if (p->N1 >= pmin * qmax && p->N1 / qmax <= 16 && nsample < (1LL << 31) && p->N2 % (kTilePoints / qmax) == 0)
             p->P = p->N1 / qmax;
     }

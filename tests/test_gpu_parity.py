@@ -601,6 +601,7 @@ def small_qmax(monkeypatch):
     ((1 << 23, 1), 30.0, np.complex64, 32, 7),       # N1 = 512 -> P = 16, one series
     ((1 << 19, 2, 2), 10.0, np.complex128, 16, 7),   # float64: N2 = 2^13, N1 = 64 -> P = 4
     ((1 << 20, 4), 10.0, np.complex128, 32, 7),      # N1 = 128 -> P = 4
+    ((1 << 19, 1, 2), 10.0, np.complex128, 32, 7),   # N1 = 64 -> P = 2: series-major / detect callers run it unsplit
 ])
 def test_split_column_transform(small_qmax, shape, dm, dtype, qmax, nk):
     small_qmax.setenv("PBH_QMAX", str(qmax))
@@ -731,3 +732,28 @@ def test_fft_native_split_column(n, tail, small_qmax):
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(np.complex64)
     _fft_check(x, 2e-6)
+
+
+@pytest.mark.gpu
+def test_default_radix2_split():
+    """2^25 complex64 samples: N1 = 2048 is split 2 x 1024 by default because the radix-2 stage rides in the layout
+    passes (5 kernels).  Series-major arrays and the detect tail have no layout pass to carry it: the same plan
+    (chirp rows in split order) runs the unsplit column passes for them."""
+    from pulsarbat_amd.transforms.dedispersion import _prepare, clear_plan_cache
+    clear_plan_cache()
+    shape, dm = (1 << 25, 1, 2), 40.0
+    rng = np.random.default_rng(77)
+    x = ((rng.standard_normal(shape, dtype=np.float32) + 1j * rng.standard_normal(shape, dtype=np.float32)) * np.float32(2 ** -0.5))
+    z = make_signal(x, 2e6, 1e9, start_time=pb.Time(56000.0, format="mjd"))
+    yr, start, stop = orc.coherent_dedispersion(x, dm, 2e6, 1e9)
+    plan, _, _, _ = _prepare(z.to_device(), pb.DM(dm), None, None, "auto")
+    assert plan.info["n1"] == 2048 and plan.info["nkernel"] == 5
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(dm))
+    assert y.shape == yr.shape and series_errors(y, yr)[0] < RTOL_L2
+    zs = type(z).like(z, z.to_device().data.to_series_major())
+    ys = pb.coherent_dedispersion(zs, pb.DM(dm))
+    assert ys.data.series_major_pitch() is not None and series_errors(ys, yr)[0] < RTOL_L2
+    a, s0 = pb.dedisperse_detect(z.to_device(), pb.DM(dm), mode="I", nscrunch=1024)
+    want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], 1024)
+    assert s0 == start and np.abs(np.asarray(a) - want).max() < 3e-5 * np.abs(want).max()
+    clear_plan_cache()
