@@ -400,6 +400,83 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
     }
 }
 
+// contrib.stft / istft with segments longer than one tile: the segments are a batch of native-length transforms
+// (de-interleave, column pass, row transforms as in fft_c2c_native) and this pass writes the spectra where the
+// reference's reshapes put them.  Plan order in: batch row b, row r (bin k1, split order P), position k2
+// -> bin k = k1 + N1*k2.  Tile: 64 "columns" J x TB positions k2 through LDS; J runs over everything that is
+// contiguous in the output for one k2, so both sides move 512-byte runs.
+//   stft  (inverse = 0): b = (c*E + e)*nseg + g;  J = ((g*nchan + c)*N1 + k1)*E + e;
+//                        out[((g*nchan + c)*n + (k + n/2) % n)*E + e] = value * scale        (fftshift, 1/n)
+//   istft (inverse = 1): b = e*nseg*nchan + g*nchan + c;  J = ((g*N1 + k1)*nchan + c)*E + e;
+//                        out[((g*n + t)*nchan + c)*E + e] = (-1)^k value * scale,  t = (n - k) % n
+//                        (the input rows were stored fftshift-ed: a factor (-1)^t = (-1)^k; the inverse transform is
+//                         the forward one read at index n - t)
+template <int TB>
+__global__ __launch_bounds__(256) void k_stft_out(const cf* __restrict__ in, cf* __restrict__ out, int N1, int N2, int P,
+                                                 int64_t nseg, int nchan, int E, int inverse, real scale) {
+    constexpr int SB = 64, LD = TB + 1, NE = SB * TB / 256;
+    __shared__ cf lds[SB * LD];
+    __shared__ int64_t src_row[SB];
+    const int64_t k20 = (int64_t)blockIdx.y * TB, J0 = (int64_t)blockIdx.x * SB;
+    const int S = nchan * E, Q = N1 / P;
+    const int64_t n = (int64_t)N1 * N2, NJ = nseg * S * N1;
+    // this thread's column (the same for every element it stores; the first 64 threads also publish its source row)
+    const int sl_own = threadIdx.x % SB;
+    const int64_t J = J0 + sl_own;
+    int64_t g = 0, dst_base = 0;
+    int c = 0, e = 0, k1 = 0;
+    if (J < NJ) {
+        if (!inverse) {
+            const int64_t gc = J / ((int64_t)N1 * E);
+            const int rem = (int)(J - gc * N1 * E);
+            k1 = rem / E;
+            e = rem - k1 * E;
+            g = gc / nchan;
+            c = (int)(gc - g * nchan);
+            dst_base = gc * n * E + e;                       // + kk * E
+        } else {
+            g = J / ((int64_t)N1 * S);
+            const int rem = (int)(J - g * N1 * S);
+            k1 = rem / S;
+            const int sq = rem - k1 * S;
+            c = sq / E;
+            e = sq - c * E;
+            dst_base = g * n * S + sq;                       // + t * S
+        }
+        if (threadIdx.x < SB) {
+            const int64_t b = inverse ? ((int64_t)e * nseg + g) * nchan + c : ((int64_t)c * E + e) * nseg + g;
+            const int r = P > 1 ? (k1 % P) * Q + k1 / P : k1;
+            src_row[sl_own] = (b * N1 + r) * N2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        const int sl = q / TB, t = q % TB;
+        if (J0 + sl < NJ && k20 + t < N2) lds[sl * LD + t] = in[src_row[sl] + k20 + t];
+    }
+    __syncthreads();
+    if (J >= NJ) return;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int t = (threadIdx.x + 256 * j) / SB;
+        const int64_t k2 = k20 + t;
+        if (k2 < N2) {
+            const cf a = lds[sl_own * LD + t];
+            const int64_t k = k1 + (int64_t)N1 * k2;
+            if (!inverse) {
+                const int64_t kk = k + n / 2 < n ? k + n / 2 : k - n / 2;
+                out[dst_base + kk * E] = make_cf(a.x * scale, a.y * scale);
+            } else {
+                const int64_t tt = k ? n - k : 0;
+                const real sg = (k & 1) ? -scale : scale;
+                out[dst_base + tt * S] = make_cf(a.x * sg, a.y * sg);
+            }
+        }
+    }
+}
+
 #ifndef PBH_F64
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the

@@ -947,4 +947,71 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     }
 }
 
+// ---- contrib.stft / istft with one segment per tile (nperseg = 2^tile) and an even number of inner elements ----
+// k_small would give each of the two polarisations of a channel to a different workgroup: 8-byte pieces at a
+// 16-byte stride on both sides (2.0 TB/s).  Here a workgroup transforms BOTH series of a pair: it loads 16 or 32
+// bytes per row (the pair is adjacent on the time-ordered side, (t*S + q), and on the channelised side,
+// ((c*M + r)*E + e)), runs the two tile FFTs one after the other through the same LDS, and stores the pair.
+struct SegPairParams {
+    const cf* in;
+    cf* out;
+    const cf* tw16k;
+    int S, E;        // series per time sample, inner elements per channel (even)
+    int inverse;     // 0 stft (x 1/M, fftshift on the way out), 1 istft (ifftshift on the way in)
+    real scale;
+};
+
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_seg_pair(SegPairParams p) {
+    static_assert(M == kTilePoints, "k_seg_pair: one segment of one series per tile");
+    constexpr int MR = M / R;
+    typedef real vec4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tau = threadIdx.x;
+    const int q = 2 * blockIdx.x;            // first series of the pair
+    const int c = q / p.E, e = q - c * p.E;
+    const int64_t seg = (int64_t)blockIdx.y * M * p.S;   // segments are consecutive (M, S) blocks on both sides
+    // element offsets of row (tau + i*MR): time-ordered (t*S + q); channelised ((c*M + r)*E + e)
+    const int64_t t_off = seg + (int64_t)tau * p.S + q, t_step = (int64_t)MR * p.S;
+    const int64_t c_off = seg + ((int64_t)c * M + tau) * p.E + e, c_step = (int64_t)MR * p.E;
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+    cf a[R], b[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const cf* src = p.inverse ? p.in + c_off + (i ^ (R / 2)) * c_step : p.in + t_off + i * t_step;   // ifftshift
+        const vec4 x = *reinterpret_cast<const vec4*>(src);
+        a[i] = make_cf(x[0], x[1]);
+        b[i] = make_cf(x[2], x[3]);
+    }
+    // (the seeds are laundered before each transform: otherwise the twiddle-power trees of the first are kept
+    //  alive for the second, ~140 VGPRs on top of the 128 the pair occupies)
+    constexpr auto seeds = std::make_integer_sequence<int, tw_seeds_or1(M, R)>{};
+    if (p.inverse) {
+        launder_all(w, seeds);
+        fft_tile<M, 1, R, +1, 1, true>(a, lds, tau, 0, w);
+        __syncthreads();
+        launder_all(w, seeds);
+        fft_tile<M, 1, R, +1, 1, true>(b, lds, tau, 0, w);
+    } else {
+        launder_all(w, seeds);
+        fft_tile<M, 1, R, -1, 1, true>(a, lds, tau, 0, w);
+        __syncthreads();
+        launder_all(w, seeds);
+        fft_tile<M, 1, R, -1, 1, true>(b, lds, tau, 0, w);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        cf* dst = p.inverse ? p.out + t_off + i * t_step : p.out + c_off + (i ^ (R / 2)) * c_step;   // fftshift
+        vec4 x;
+        x[0] = a[i].x * p.scale;
+        x[1] = a[i].y * p.scale;
+        x[2] = b[i].x * p.scale;
+        x[3] = b[i].y * p.scale;
+        *reinterpret_cast<vec4*>(dst) = x;
+    }
+}
+
 }  // namespace PBH_NS

@@ -1887,21 +1887,23 @@ static bool native_fft_ok(int64_t n, int64_t batch) {
     return (is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0;
 }
 
-static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
-    pbh_plan* p = nullptr;
-    PBHCHECK(native_fft_plan(device, n, batch, &p));
+// Forward transforms of a native-length plan `p` (batch = p->S series of p->N samples) up to plan order in p->work.
+// The input is `il` interleaved streams of `total` = (p->S / il) * p->N samples each: de-interleaved, stream s
+// becomes the batch rows s*(p->S/il) .. (pbh_fft_c2c: il = batch, one row per stream; stft: rows = segments).
+static int native_forward(pbh_plan* p, const cf* din, int il, hipStream_t st) {
     const int S = p->S, N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
+    const int64_t n = p->N, total = (int64_t)(S / il) * n;
     cf* work = p->work;
     BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, n - 1};
     tw.nmod = is_pow2(n) ? 0 : n;
-    const bool fuse = P > 1 && S > 1 && radix_layout_ok(S, P, n, N2);
+    const bool fuse = P > 1 && il == S && S > 1 && radix_layout_ok(S, P, n, N2);
     const cf* src = work;   // what the column pass reads
     if (fuse) {
         PBHCHECK(launch_deint_radix(S, P, din, work, n, N2, N1, n, st));
     } else {
-        if (S > 1) PBHCHECK(launch_deinterleave(din, work, n, S, n, st));   // (one series is its own planar form)
-        if (P > 1) PBHCHECK(launch_radix<-1>(P, S > 1 ? work : din, n, work, n, S, n, N2, N1, 0, n, st));
-        else if (S == 1) src = din;
+        if (il > 1) PBHCHECK(launch_deinterleave(din, work, total, il, total, st));   // (one stream is its own planar form)
+        if (P > 1) PBHCHECK(launch_radix<-1>(P, il > 1 ? work : din, n, work, n, S, n, N2, N1, 0, n, st));
+        else if (il == 1) src = din;
     }
     const bool colq = P > 1 || (Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && n < (1LL << 31));
     if (colq) {
@@ -1919,11 +1921,47 @@ static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, i
         ColParams c1{src, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, (int64_t)S * N2, 0, tw, p->tw16k, 0, n, 0};
         PBHCHECK(launch_col<OP_FWD_TW>(N1, c1, st));
     }
-    PBHCHECK(launch_rowfft(N2, work, p->tw16k, (int64_t)S * N1, st));
+    return launch_rowfft(N2, work, p->tw16k, (int64_t)S * N1, st);
+}
+
+static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t n, int64_t batch, int inverse) {
+    pbh_plan* p = nullptr;
+    PBHCHECK(native_fft_plan(device, n, batch, &p));
+    PBHCHECK(native_forward(p, din, p->S, st));
     constexpr int SB = 64, TB = kBlkElems / 64;
-    const int64_t ncol = (int64_t)N1 * S;
-    hipLaunchKernelGGL((k_fft_out<SB, TB>), dim3((unsigned)((ncol + SB - 1) / SB), (unsigned)((N2 + TB - 1) / TB)), dim3(256), 0, st,
-                       (const cf*)work, dout, N1, N2, S, P, inverse, inverse ? (real)(1.0 / (double)n) : (real)1);
+    const int64_t ncol = (int64_t)p->N1 * p->S;
+    hipLaunchKernelGGL((k_fft_out<SB, TB>), dim3((unsigned)((ncol + SB - 1) / SB), (unsigned)((p->N2 + TB - 1) / TB)), dim3(256), 0, st,
+                       (const cf*)p->work, dout, p->N1, p->N2, p->S, p->P, inverse, inverse ? (real)(1.0 / (double)n) : (real)1);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+static bool stft_pair_enabled() {
+    static const bool on = [] { const char* e = getenv("PBH_STFT_PAIR"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
+// contrib.stft / istft with native segment lengths beyond one tile: the segments are the batch
+static bool stft_native_ok(int64_t n, int64_t nseg, int64_t S) {
+    static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
+    if (!on || n <= kTilePoints || n > (1LL << 27) || nseg * S > 0x7fffffffLL || nseg * S * (n / kTilePoints + 1) / 64 > 0x7fffffffLL)
+        return false;
+    return (is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0;
+}
+
+static int stft_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t nseg, int64_t n, int nchan, int inner,
+                       int inverse) {
+    const int64_t B = nseg * nchan * inner;
+    pbh_plan* p = nullptr;
+    PBHCHECK(native_fft_plan(device, n, B, &p));
+    // stft: the (nseg*n, S) array de-interleaves into S streams whose segments are the batch rows (s*nseg + g);
+    // istft: the (nseg*nchan*n, E) array into E streams of nseg*nchan rows
+    PBHCHECK(native_forward(p, din, inverse ? inner : nchan * inner, st));
+    constexpr int TB = 64;
+    const int64_t NJ = B * p->N1;
+    hipLaunchKernelGGL((k_stft_out<TB>), dim3((unsigned)((NJ + 63) / 64), (unsigned)((p->N2 + TB - 1) / TB)), dim3(256), 0, st,
+                       (const cf*)p->work, dout, p->N1, p->N2, p->P, nseg, nchan, inner, inverse,
+                       inverse ? (real)1 : (real)(1.0 / (double)n));
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -2052,7 +2090,19 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
                 rc = fail(PBH_ERR_HIP, "hipMemcpy(twiddles) failed");
             tw_dev = device;
         }
-        if (rc == PBH_OK) {
+        if (rc == PBH_OK && n == kTilePoints && inner % 2 == 0 && stft_pair_enabled()) {
+            // one segment of one series fills a tile: a workgroup takes both series of a pair (k_seg_pair)
+            auto kern = k_seg_pair<kTilePoints, PBH_R>;
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tile_bytes<true>()) != hipSuccess)
+                rc = fail(PBH_ERR_HIP, "hipFuncSetAttribute(k_seg_pair) failed");
+            for (int64_t g0 = 0; g0 < nseg && rc == PBH_OK; g0 += 65535) {
+                const int64_t cnt = nseg - g0 < 65535 ? nseg - g0 : 65535;
+                SegPairParams sp{din + g0 * n * S, dout + g0 * n * S, tw, (int)S, inner, inverse ? 1 : 0,
+                                 inverse ? (real)1 : (real)(1.0 / (double)n)};
+                hipLaunchKernelGGL(kern, dim3((unsigned)(S / 2), (unsigned)cnt), dim3(kTilePoints / PBH_R), lds_tile_bytes<true>(), st, sp);
+                if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "k_seg_pair failed to launch");
+            }
+        } else if (rc == PBH_OK) {
             // a tile holds F = tile/n columns: with F > S it spans F/S whole segments; grid.y walks the
             // segment groups, at most 65535 per launch
             const int64_t F = kTilePoints / n;
@@ -2069,6 +2119,8 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
                 rc = launch_small((int)n, sp, st, (cnt + segs - 1) / segs);
             }
         }
+    } else if (stft_native_ok(n, nseg, S)) {
+        rc = stft_native(device, st, din, dout, nseg, n, nchan, inner, inverse);
     } else if (n > (1LL << 27)) {
         rc = fail(PBH_ERR_UNSUPPORTED, "nperseg too large");
     } else {

@@ -89,3 +89,44 @@ class TestSTFT:
         assert np.linalg.norm(np.asarray(s) - want) / np.linalg.norm(want) < 3e-6
         y = pb.contrib.istft(s, nperseg=n)
         assert np.linalg.norm(np.asarray(y) - x[: len(y)]) / np.linalg.norm(x) < 3e-6
+
+    @pytest.mark.parametrize("n,tail,nseg,dtype", [
+        (1 << 15, (2, 2), 5, np.complex64), (1 << 16, (1, 2), 3, np.complex64), (1 << 17, (3,), 2, np.complex64),
+        (1 << 15, (1, 1), 4, np.complex64), (3 << 19, (1, 2), 2, np.complex64), (1 << 20, (2, 2), 3, np.complex64),
+        (1 << 14, (2, 2), 3, np.complex128), (1 << 16, (1, 2), 2, np.complex128),
+    ])
+    def test_segments_beyond_one_tile(self, n, tail, nseg, dtype):
+        """Native segment lengths longer than a tile: the segments are a batch of multi-pass transforms and one
+        pass writes fftshift / scale / the reference's layout (k_stft_out)."""
+        rng = np.random.default_rng(n % 977 + nseg)
+        shape = (n * nseg + 17,) + tail
+        x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+        z = pb.BasebandSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+        s = pb.contrib.stft(z.to_device(), nperseg=n)
+        want = orc.stft(x, n)
+        tol = 3e-6 if dtype == np.complex64 else 1e-12
+        assert s.shape == want.shape and np.linalg.norm(np.asarray(s) - want) / np.linalg.norm(want) < tol
+        # every bin in its place: a tone at bin 5 of channel 0 (fftshift puts it at n/2 + 5)
+        t = np.zeros(shape, dtype)
+        t[:n * nseg, 0] = np.exp(2j * np.pi * 5 * np.arange(n * nseg) / n).reshape((-1,) + (1,) * (len(tail) - 1))
+        st = np.asarray(pb.contrib.stft(pb.BasebandSignal(t, sample_rate=1 * u.MHz, center_freq=1 * u.GHz).to_device(), nperseg=n))
+        peak = np.zeros_like(st)
+        peak[:, n // 2 + 5] = 1
+        assert np.abs(st - peak).max() < (1e-4 if dtype == np.complex64 else 1e-10)
+        y = pb.contrib.istft(s, nperseg=n)
+        assert np.linalg.norm(np.asarray(y) - x[: len(y)]) / np.linalg.norm(x[: len(y)]) < tol
+
+    @pytest.mark.parametrize("n,dtype,tail", [(16384, np.complex64, (1, 2)), (16384, np.complex64, (3, 4)),
+                                              (8192, np.complex128, (1, 2)), (8192, np.complex128, (2, 2))])
+    def test_one_segment_per_tile_pairs(self, n, dtype, tail):
+        """nperseg = one tile with an even number of inner elements: both series of a pair in one workgroup (k_seg_pair)."""
+        rng = np.random.default_rng(3)
+        shape = (n * 5 + 11,) + tail
+        x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+        z = pb.BasebandSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+        s = pb.contrib.stft(z.to_device(), nperseg=n)
+        want = orc.stft(x, n)
+        tol = 3e-6 if dtype == np.complex64 else 1e-12
+        assert np.linalg.norm(np.asarray(s) - want) / np.linalg.norm(want) < tol
+        y = pb.contrib.istft(s, nperseg=n)
+        assert np.linalg.norm(np.asarray(y) - x[: len(y)]) / np.linalg.norm(x[: len(y)]) < tol
