@@ -140,6 +140,11 @@ int pbh_pol_basis(int device, void* hip_stream, int dtype, const void* in_dev, v
 int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
                    int unit_words, const int64_t* delay);
 
+/* pbh_fft_c2c and pbh_stft keep, per calling thread, up to two Bluestein and two multi-pass transform plans
+ * (twiddle tables and a workspace the size of the data) for reuse by the next call of the same shape.
+ * pbh_trim() releases the calling thread's cached plans.                                                   */
+int pbh_trim(void);
+
 /* Blocking copy between caller (host) memory and device memory, direction 0 = host->device, 1 =
  * device->host, ordered on hip_stream.  Goes through the library's own pinned bounce buffers, like every
  * PBH_HOST argument of the calls below: pageable caller memory is never handed to the HIP runtime, whose

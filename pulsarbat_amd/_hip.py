@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "fft_c2c",
+__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "trim", "fft_c2c",
            "chirp_function", "copy_bench"]
 
 HOST, DEVICE = 0, 1
@@ -78,6 +78,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_int64)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
+    "pbh_trim": (C.c_int, []),
     "pbh_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "pbh_decode": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_RawLayout), C.c_int64,
                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
@@ -167,6 +168,12 @@ def _ptr_loc(a):
     raise TypeError(f"unsupported array type {type(a)!r}")
 
 
+def trim():
+    """Free the calling thread's cached stand-alone transform plans (pbh_trim)."""
+    if _lib is not None:
+        _check(lib().pbh_trim())
+
+
 def transfer(device, dst_ptr, src_ptr, nbytes, to_host):
     """Blocking host<->device copy through the library's pinned bounce buffers (pbh_transfer)."""
     _require_device()
@@ -200,7 +207,10 @@ class Plan:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            lib().pbh_plan_destroy(self._h)
+            try:
+                lib().pbh_plan_destroy(self._h)
+            except Exception:   # interpreter shutdown: module globals may be gone, the process frees the memory
+                pass
             self._h = C.c_void_p()
 
     __del__ = close

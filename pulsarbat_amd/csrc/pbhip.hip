@@ -24,6 +24,7 @@
 #define pbh_incoherent PBH_FN(incoherent)
 #define pbh_transfer PBH_FN(transfer)
 #define pbh_decode PBH_FN(decode)
+#define pbh_trim PBH_FN(trim)
 #define pbh_dedisperse_stream_raw PBH_FN(dedisperse_stream_raw)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
@@ -1829,15 +1830,33 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
 // Lengths beyond one tile, or not a power of two: Bluestein ring as a plain transform
 // (forward X = b * conv(x b); inverse x = conj(b * conv(conj(X) b)) / n).  Plans are cached per thread.
 // per-thread cache of plain-transform ring plans (n points, `batch` columns)
+// Per-thread caches of the plans behind the plan-less entry points (pbh_fft_c2c, pbh_stft): two Bluestein ring
+// plans and two native transform plans, each owning a workspace the size of its data.  pbh_trim() frees them.
+struct CachedPlan { int device; int64_t n, batch; pbh_plan* plan; };
+static thread_local CachedPlan g_ring_cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+static thread_local CachedPlan g_native_cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+
+int pbh_trim(void) {
+    for (auto* cache : {g_ring_cache, g_native_cache})
+        for (int i = 0; i < 2; ++i)
+            if (cache[i].plan) {
+                pbh_plan_destroy(cache[i].plan);
+                cache[i] = CachedPlan{-1, 0, 0, nullptr};
+            }
+    return PBH_OK;
+}
+
 static int ring_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
-    struct Entry { int device; int64_t n, batch; pbh_plan* plan; };
-    static thread_local Entry cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+    typedef CachedPlan Entry;
+    CachedPlan* cache = g_ring_cache;
     static thread_local int next = 0;
-    for (auto& e : cache)
+    for (int i = 0; i < 2; ++i) {
+        auto& e = cache[i];
         if (e.plan && e.device == device && e.n == n && e.batch == batch) {
             *out = e.plan;
             return PBH_OK;
         }
+    }
     if (batch > 0x7fffffffLL) return fail(PBH_ERR_UNSUPPORTED, "too many columns for one ring plan");
 #ifdef PBH_F64
     const int dt = PBH_C128;
@@ -1858,14 +1877,16 @@ static int ring_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
 // de-interleave (+ radix stage), column pass, row transforms, natural-order output (k_fft_out).  Plans
 // (workspace and twiddles only) are cached per thread like the ring plans.
 static int native_fft_plan(int device, int64_t n, int64_t batch, pbh_plan** out) {
-    struct Entry { int device; int64_t n, batch; pbh_plan* plan; };
-    static thread_local Entry cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
+    typedef CachedPlan Entry;
+    CachedPlan* cache = g_native_cache;
     static thread_local int next = 0;
-    for (auto& e : cache)
+    for (int i = 0; i < 2; ++i) {
+        auto& e = cache[i];
         if (e.plan && e.device == device && e.n == n && e.batch == batch) {
             *out = e.plan;
             return PBH_OK;
         }
+    }
 #ifdef PBH_F64
     const int dt = PBH_C128;
 #else

@@ -23,6 +23,7 @@
     int P##pol_basis(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##transfer(int, void*, void*, const void*, size_t, int);                                               \
+    int P##trim(void);                                                                                          \
     int P##decode(int, void*, const void*, size_t, int, const pbh_raw_layout_t*, int64_t, int64_t, int, int,    \
                   const unsigned char*, float, void*, int, int64_t);                                            \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
@@ -149,6 +150,11 @@ int pbh_decode(int device, void* stream, const void* raw, size_t raw_bytes, int 
                int out_layout, int64_t out_pitch) {
     return done(PBH_C64, pbh32_decode(device, stream, raw, raw_bytes, raw_loc, layout, first, nsample, nchan, npol, conj_mask,
                                       scale, out, out_layout, out_pitch));
+}
+int pbh_trim(void) {
+    pbh32_trim();
+    pbh64_trim();
+    return PBH_OK;
 }
 int pbh_transfer(int device, void* stream, void* dst, const void* src, size_t bytes, int direction) {
     return done(PBH_C64, pbh32_transfer(device, stream, dst, src, bytes, direction));

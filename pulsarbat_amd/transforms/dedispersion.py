@@ -149,9 +149,11 @@ def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
 
 
 def clear_plan_cache():
+    """Destroy the cached dedispersion plans and the library's own per-thread transform plans."""
     while _PLANS:
         _, ent = _PLANS.popitem()
         ent[0].close()
+    _hip.trim()
 
 
 def _crop_bounds(z, dm, ref_freq):

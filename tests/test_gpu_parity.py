@@ -757,3 +757,23 @@ def test_default_radix2_split():
     want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], 1024)
     assert s0 == start and np.abs(np.asarray(a) - want).max() < 3e-5 * np.abs(want).max()
     clear_plan_cache()
+
+
+@pytest.mark.gpu
+def test_trim_releases_cached_transform_plans():
+    """pbh_fft_c2c keeps per-thread plans (workspace = data size); pbh_trim frees them and the next call rebuilds."""
+    import torch
+    from pulsarbat_amd import _hip
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((1 << 20, 8)) + 1j * rng.standard_normal((1 << 20, 8))).astype(np.complex64)
+    d = pb.DeviceArray.from_host(x)
+    _hip.trim()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    a = np.asarray(pb.fft.fft(d, axis=0))
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 >= x.nbytes          # the cached plan's workspace
+    _hip.trim()
+    assert torch.cuda.mem_get_info()[0] - free1 >= x.nbytes
+    b = np.asarray(pb.fft.fft(d, axis=0))
+    assert np.array_equal(a, b)
