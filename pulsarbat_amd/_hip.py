@@ -8,6 +8,7 @@ is present, every hot-path call raises :class:`HipUnavailableError`.
 import ctypes as C
 import os
 import threading
+from collections import OrderedDict
 
 import numpy as np
 
@@ -168,8 +169,36 @@ def _ptr_loc(a):
     raise TypeError(f"unsupported array type {type(a)!r}")
 
 
+_FILTER_PLANS = OrderedDict()
+_FILTER_PLAN_CACHE_SIZE = 2
+
+
+def filter_plan(nsample, nseries, lo, hi, device, dtype):
+    """Cached plan with one filter row per series (nchan = nseries, npol = 1) for the FFT * H * IFFT helpers
+    (time_shift, freq_shift, real_to_complex): creating one costs two allocations the size of the data, so the
+    last few geometries are kept.  The caller sets H (chirp_special / chirp_upload) before every use."""
+    key = (int(nsample), int(nseries), int(lo), int(hi), int(device), np.dtype(dtype).str, threading.get_ident())
+    with _lock:
+        plan = _FILTER_PLANS.pop(key, None)
+    if plan is None:
+        plan = Plan(nsample, nseries, 1, lo, hi, device=device, dtype=dtype)
+    with _lock:
+        _FILTER_PLANS[key] = plan
+        stale = []
+        while len(_FILTER_PLANS) > _FILTER_PLAN_CACHE_SIZE:
+            stale.append(_FILTER_PLANS.popitem(last=False)[1])
+    for old in stale:
+        old.close()
+    return plan
+
+
 def trim():
     """Free the calling thread's cached stand-alone transform plans (pbh_trim)."""
+    with _lock:
+        stale = list(_FILTER_PLANS.values())
+        _FILTER_PLANS.clear()
+    for old in stale:
+        old.close()
     if _lib is not None:
         _check(lib().pbh_trim())
 

@@ -1123,17 +1123,37 @@ __global__ __launch_bounds__(256) void k_zero_edges(cf* __restrict__ data, const
 // ---- incoherent dedispersion (pulsarbat/transforms/dedispersion.py:136-177): per-channel integer shift ----
 // out[n, c, :] = in[n + delay[c], c, :], n < nout.  A pure gather: rows of `unit` 4-byte words per
 // (sample, channel) (float32 Stokes: inner words; complex64: 2*inner; float64: 2*inner; ...).
-__global__ __launch_bounds__(256) void k_incoherent(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+// T = uint4 when a (sample, channel) cell is a whole number of 16-byte vectors and the arrays are aligned, else
+// uint32_t.  A workgroup copies 256*U consecutive elements of the output: the (sample, position in row) pair of a
+// thread's first element costs one division, the following ones advance incrementally; all loads before the stores.
+template <typename T, int U>
+__global__ __launch_bounds__(256) void k_incoherent(const T* __restrict__ in, T* __restrict__ out,
                                                     const int64_t* __restrict__ delay, int64_t nout, int nchan,
-                                                    int unit) {
-    const int64_t row = (int64_t)nchan * unit;  // words per time sample
+                                                    int unit /* elements of T per (sample, channel) */) {
+    const int64_t row = (int64_t)nchan * unit;  // elements per time sample
     const int64_t total = nout * row;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = e / row;
-        const int r = (int)(e - n * row);
-        const int c = r / unit;
-        out[e] = in[(n + delay[c]) * row + r];
+    const int64_t e0 = ((int64_t)blockIdx.x * U) * 256 + threadIdx.x;
+    int64_t n = e0 / row;
+    int64_t r = e0 - n * row;
+    const int64_t dn = 256 / row, dr = 256 - dn * row;   // advance of 256 elements
+    T v[U];
+    int64_t eo[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int64_t e = e0 + 256 * (int64_t)j;
+        eo[j] = e < total ? e : -1;
+        const int64_t nn = n < nout ? n : nout - 1;   // (tail lanes re-read the last row: no branch around the load)
+        v[j] = in[(nn + delay[(int)(r / unit)]) * row + r];
+        n += dn;
+        r += dr;
+        if (r >= row) {
+            r -= row;
+            ++n;
+        }
     }
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+        if (eo[j] >= 0) out[eo[j]] = v[j];
 }
 #endif  // !PBH_F64
 

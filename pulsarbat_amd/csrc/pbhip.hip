@@ -1573,18 +1573,37 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
     if (nout == 0) return PBH_OK;
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
-    int64_t* d = nullptr;
-    PBHCHECK(dev_alloc(nullptr, (void**)&d, sizeof(int64_t) * (size_t)nchan));
-    hipError_t e = hipMemcpyAsync(d, delay, sizeof(int64_t) * (size_t)nchan, hipMemcpyHostToDevice, st);
+    // per-thread device copy of the delays, grown on demand (copies and kernels are ordered on the stream)
+    static thread_local int64_t* d = nullptr;
+    static thread_local int d_cap = 0, d_dev = -1;
+    static thread_local hipStream_t d_stream = nullptr;
+    if (d && d_stream != st) HIPCHECK(hipStreamSynchronize(d_stream));   // the previous user may still be reading
+    if (!d || d_cap < nchan || d_dev != device) {
+        if (d) {
+            HIPCHECK(hipDeviceSynchronize());
+            hipFree(d);
+            d = nullptr;
+        }
+        PBHCHECK(dev_alloc(nullptr, (void**)&d, sizeof(int64_t) * (size_t)nchan));
+        d_cap = nchan;
+        d_dev = device;
+    }
+    d_stream = st;
+    hipError_t e = xfer_h2d(d, delay, sizeof(int64_t) * (size_t)nchan, st);
     if (e == hipSuccess) {
-        int64_t blocks = (nout * nchan * unit_words + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(k_incoherent, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)in_dev,
-                           (uint32_t*)out_dev, (const int64_t*)d, nout, nchan, unit_words);
+        constexpr int U = 8;
+        const bool vec = unit_words % 4 == 0 && ((uintptr_t)in_dev | (uintptr_t)out_dev) % 16 == 0;
+        const int unit = vec ? unit_words / 4 : unit_words;
+        const int64_t total = nout * nchan * unit;
+        const unsigned blocks = (unsigned)((total + 256 * U - 1) / (256 * U));
+        if (vec)
+            hipLaunchKernelGGL((k_incoherent<uint4, U>), dim3(blocks), dim3(256), 0, st, (const uint4*)in_dev, (uint4*)out_dev,
+                               (const int64_t*)d, nout, nchan, unit);
+        else
+            hipLaunchKernelGGL((k_incoherent<uint32_t, U>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)in_dev,
+                               (uint32_t*)out_dev, (const int64_t*)d, nout, nchan, unit);
         e = hipGetLastError();
     }
-    hipStreamSynchronize(st);
-    hipFree(d);
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_incoherent: ") + hipGetErrorString(e));
     return PBH_OK;
 }

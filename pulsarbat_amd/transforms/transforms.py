@@ -76,9 +76,9 @@ def time_shift(z, /, shift, crop=False):
     x, on_dev, real, dt = _to_device_complex(z)
     S = sh.size
     lo, hi = (start, N + stop) if crop else (0, N)
-    with _hip.Plan(N, S, 1, lo, hi, device=x.device_index, dtype=x.dtype) as plan:
-        plan.chirp_special(sh, 0)
-        y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
+    plan = _hip.filter_plan(N, S, lo, hi, x.device_index, x.dtype)
+    plan.chirp_special(sh, 0)
+    y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
     y = DeviceArray(y.tensor.reshape(hi - lo if hi > lo else 0, S))
     if not crop:
         _hip.zero_edges(y, sh)
@@ -113,9 +113,9 @@ def freq_shift(z, /, shift):
     S = ft.size
     xm = DeviceArray(x.tensor.reshape(N, S).clone())  # the mixer works in place: keep the caller's data
     _hip.mix(xm, ft)
-    with _hip.Plan(N, S, 1, 0, N, device=xm.device_index, dtype=xm.dtype) as plan:
-        plan.chirp_special(ft * N, 1)
-        y = plan.dedisperse(DeviceArray(xm.tensor.reshape(N, S, 1)))
+    plan = _hip.filter_plan(N, S, 0, N, xm.device_index, xm.dtype)
+    plan.chirp_special(ft * N, 1)
+    y = plan.dedisperse(DeviceArray(xm.tensor.reshape(N, S, 1)))
     out = _from_device(DeviceArray(y.tensor.reshape(N, S)), on_dev, False, dt, (N,) + tuple(z.sample_shape))
     return type(z).like(z, out)
 
