@@ -173,15 +173,19 @@ _FILTER_PLANS = OrderedDict()
 _FILTER_PLAN_CACHE_SIZE = 2
 
 
-def filter_plan(nsample, nseries, lo, hi, device, dtype):
-    """Cached plan with one filter row per series (nchan = nseries, npol = 1) for the FFT * H * IFFT helpers
-    (time_shift, freq_shift, real_to_complex): creating one costs two allocations the size of the data, so the
-    last few geometries are kept.  The caller sets H (chirp_special / chirp_upload) before every use."""
-    key = (int(nsample), int(nseries), int(lo), int(hi), int(device), np.dtype(dtype).str, threading.get_ident())
+def filter_plan(nsample, nseries, lo, hi, device, dtype, shared=False):
+    """Cached plan for the FFT * H * IFFT helpers (time_shift, freq_shift, real_to_complex): one filter row per
+    series (nchan = nseries, npol = 1), or with ``shared`` ONE row for all series (nchan = 1, npol = nseries: the
+    row pass then reads 8/nseries bytes of filter per sample instead of 8).  Creating a plan costs two allocations
+    the size of the data, so the last few geometries are kept.  The caller sets H (chirp_special / chirp_upload)
+    before every use."""
+    key = (int(nsample), int(nseries), int(lo), int(hi), int(device), np.dtype(dtype).str, bool(shared),
+           threading.get_ident())
     with _lock:
         plan = _FILTER_PLANS.pop(key, None)
     if plan is None:
-        plan = Plan(nsample, nseries, 1, lo, hi, device=device, dtype=dtype)
+        plan = (Plan(nsample, 1, nseries, lo, hi, device=device, dtype=dtype) if shared else
+                Plan(nsample, nseries, 1, lo, hi, device=device, dtype=dtype))
     with _lock:
         _FILTER_PLANS[key] = plan
         stale = []

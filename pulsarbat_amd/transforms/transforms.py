@@ -76,9 +76,10 @@ def time_shift(z, /, shift, crop=False):
     x, on_dev, real, dt = _to_device_complex(z)
     S = sh.size
     lo, hi = (start, N + stop) if crop else (0, N)
-    plan = _hip.filter_plan(N, S, lo, hi, x.device_index, x.dtype)
-    plan.chirp_special(sh, 0)
-    y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
+    same = bool(np.all(sh == sh[0]))   # one shift for every series: a single shared phase ramp
+    plan = _hip.filter_plan(N, S, lo, hi, x.device_index, x.dtype, shared=same)
+    plan.chirp_special(sh[:1] if same else sh, 0)
+    y = plan.dedisperse(DeviceArray(x.tensor.reshape((N, 1, S) if same else (N, S, 1))))
     y = DeviceArray(y.tensor.reshape(hi - lo if hi > lo else 0, S))
     if not crop:
         _hip.zero_edges(y, sh)

@@ -38,9 +38,9 @@ def real_to_complex(z, axis=0):
         lead = a.shape[1:]
         x = DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, -1)).astype(out_dtype))
     S = x.shape[1]
-    plan = _hip.filter_plan(N, S, 0, N, x.device_index, out_dtype)
-    plan.chirp_special(np.zeros(S), 2)
-    y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, S, 1)))
+    plan = _hip.filter_plan(N, S, 0, N, x.device_index, out_dtype, shared=True)   # the same Hilbert weights for all
+    plan.chirp_special(np.zeros(1), 2)
+    y = plan.dedisperse(DeviceArray(x.tensor.reshape(N, 1, S)))
     out = _hip.decimate2(DeviceArray(y.tensor.reshape(N, S)))
     nout = out.shape[0]
     if on_dev:
