@@ -1057,6 +1057,7 @@ __global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const doub
             double sn, cs;
             sincospi(2.0 * fr, &sn, &cs);
             p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
+            if (p.phase) p.phase[d] = (float)(-fr);
         } else if (mode == 1) {
             const int64_t i = (k + p.N / 2) % p.N;
             bool zero;

@@ -1470,11 +1470,20 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipMemcpyAsync(p->chan_freq, arg, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, 0.0, 0.0, 0.0, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
     cp.P = p->P;
+    bool phase = false;
+#ifndef PBH_F64
+    // the time-shift ramp has unit magnitude: the row pass can read it as a phase, like a generated chirp
+    if (mode == 0 && p->N1 > 1 && p->N2 == kTilePoints && p->perm_w == 0 && !p->bsL) {
+        if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
+        cp.phase = p->chirp_phase;
+        phase = true;
+    }
+#endif
     hipLaunchKernelGGL(k_chirp_special, dim3(2048), dim3(256), 0, p->stream, cp, (const double*)p->chan_freq, mode);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
-    p->has_phase = false;
+    p->has_phase = phase;
     PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
 }

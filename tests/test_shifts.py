@@ -191,3 +191,21 @@ class TestSnippet:
             pb.snippet(z, np.arange(10), 10)
         with pytest.raises(ValueError):
             pb.snippet(z, Time.now(), 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,shift", [((1 << 19, 2, 2), 3.37), ((1 << 20, 3), np.array([-7.25, 0.5, 12.0])),
+                                         ((1 << 19, 2, 2), -1000.5)])
+def test_time_shift_multi_pass_lengths(shape, shift):
+    """Lengths beyond one tile: the phase ramp is read as a float32 phase by the fused row pass (uniform shift: one
+    shared row) or as per-series rows; noise input against the oracle."""
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    z = pb.Signal(x, sample_rate=1 * u.kHz)
+    want, start, stop = orc.time_shift(x, shift)
+    for zz in (z, pb.Signal(pb.DeviceArray.from_host(x), sample_rate=1 * u.kHz)):
+        y = np.asarray(pb.time_shift(zz, shift))
+        assert np.linalg.norm(y - want) / np.linalg.norm(want) < 2e-6
+        yc = np.asarray(pb.time_shift(zz, shift, crop=True))
+        assert yc.shape[0] == shape[0] - start + stop
+        assert np.linalg.norm(yc - want[start:shape[0] + stop]) / np.linalg.norm(want) < 2e-6
