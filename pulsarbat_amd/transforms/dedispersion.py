@@ -11,6 +11,7 @@ dedispersion.py:19-23 (``_transfer_function``).  There is no CPU fallback.
 
 import math
 from collections import OrderedDict
+import threading
 
 import numpy as np
 
@@ -107,6 +108,7 @@ DM = DispersionMeasure
 
 # ---- plan cache --------------------------------------------------------------------------------
 _PLANS = OrderedDict()
+_PLANS_LOCK = threading.Lock()
 _PLAN_CACHE_SIZE = 4
 
 
@@ -129,8 +131,10 @@ def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
     dt = u.to_value(z.dt, u.s)
     ref = _hz(ref_freq)
     ckey = None if chirp is not None else (coeff, dt, freqs.tobytes(), ref)
-    key = (nsample, nchan, npol, crop, dev, variant, np.dtype(z.dtype).str)
-    ent = _PLANS.pop(key, None)
+    # (a plan is not re-entrant: the cache is per thread, so concurrent callers never share one)
+    key = (nsample, nchan, npol, crop, dev, variant, np.dtype(z.dtype).str, threading.get_ident())
+    with _PLANS_LOCK:
+        ent = _PLANS.pop(key, None)
     if ent is None:
         plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant, dtype=z.dtype)
         ent = [plan, object()]
@@ -141,17 +145,23 @@ def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
     elif ent[1] != ckey:
         plan.chirp_generate(coeff, dt, freqs, ref)
         ent[1] = ckey
-    _PLANS[key] = ent
-    while len(_PLANS) > _PLAN_CACHE_SIZE:
-        _, old = _PLANS.popitem(last=False)
+    stale = []
+    with _PLANS_LOCK:
+        _PLANS[key] = ent
+        mine = [k for k in _PLANS if k[-1] == key[-1]]
+        while len(mine) > _PLAN_CACHE_SIZE:      # the limit is per thread
+            stale.append(_PLANS.pop(mine.pop(0)))
+    for old in stale:
         old[0].close()
     return plan, isinstance(z.data, DeviceArray)
 
 
 def clear_plan_cache():
     """Destroy the cached dedispersion plans and the library's own per-thread transform plans."""
-    while _PLANS:
-        _, ent = _PLANS.popitem()
+    with _PLANS_LOCK:
+        stale = list(_PLANS.values())
+        _PLANS.clear()
+    for ent in stale:
         ent[0].close()
     _hip.trim()
 

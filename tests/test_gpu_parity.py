@@ -777,3 +777,37 @@ def test_trim_releases_cached_transform_plans():
     assert torch.cuda.mem_get_info()[0] - free1 >= x.nbytes
     b = np.asarray(pb.fft.fft(d, axis=0))
     assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_concurrent_threads():
+    """Distinct threads dedisperse concurrently (ctypes releases the GIL; a dask-threads-like caller): plans are
+    cached per thread, never shared, and every thread gets the oracle's result -- same geometry in all threads,
+    which is the case a shared plan would break."""
+    import threading
+    shape, dm, sr, fc = (1 << 17, 4, 2), 15.0, 1e6, 1e9
+    xs = [orc.synthetic_block(shape, 100 + i) for i in range(4)]
+    wants = [orc.coherent_dedispersion(x, dm, sr, fc)[0] for x in xs]
+    errs, fails = [None] * 4, []
+
+    def work(i):
+        try:
+            z = make_signal(xs[i], sr, fc)
+            worst = 0.0
+            for rep in range(6):
+                y = pb.coherent_dedispersion(z.to_device() if rep % 2 else z, pb.DM(dm))
+                worst = max(worst, series_errors(y, wants[i])[0])
+                f = np.asarray(pb.fft.fft(pb.DeviceArray.from_host(xs[i][:1 << 16, 0]), axis=0))
+                ref = np.fft.fft(xs[i][:1 << 16, 0], axis=0)
+                worst = max(worst, np.linalg.norm(f - ref) / np.linalg.norm(ref))
+            errs[i] = worst
+        except Exception as exc:   # surfaced below: an exception in a thread must fail the test
+            fails.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not fails, fails
+    assert all(e is not None and e < 2e-6 for e in errs), errs
