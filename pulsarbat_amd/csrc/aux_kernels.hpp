@@ -496,7 +496,15 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int e = 2 * (threadIdx.x + 256 * j);
-            v[j] = (n0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : make_float4(0, 0, 0, 0);
+            if (S == 1) {
+                // the two halves of a vector are consecutive time samples: with an odd number of samples the last
+                // vector holds one of them (read on its own: the element after it is not part of the input)
+                const int64_t t = n0 + e;
+                const cf a = t < nvalid ? in[t] : make_cf(0, 0), b = t + 1 < nvalid ? in[t + 1] : make_cf(0, 0);
+                v[j] = make_float4(a.x, a.y, b.x, b.y);
+            } else {
+                v[j] = (n0 + e / S < nvalid) ? src[threadIdx.x + 256 * j] : make_float4(0, 0, 0, 0);
+            }
         }
     }
 #pragma unroll

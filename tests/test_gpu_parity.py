@@ -811,3 +811,25 @@ def test_concurrent_threads():
         t.join()
     assert not fails, fails
     assert all(e is not None and e < 2e-6 for e in errs), errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [(1 << 20) + 1, (5 << 19) + 3])
+def test_odd_length_single_series_padding(n):
+    """One series of odd length whose convolution plan is a split one (L = 3 * 2^k): the zero padding happens in the
+    de-interleave pass, where a 16-byte vector holds two time samples -- the last one must not read the element
+    after the input.  The input is a view of a larger buffer whose next element is huge."""
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal(n + 1) + 1j * rng.standard_normal(n + 1)).astype(np.complex64)
+    x[n] = 1e6 + 1e6j
+    big = pb.DeviceArray.from_host(x)
+    view = big[:n]
+    assert view.data_ptr() == big.data_ptr()
+    z = pb.BasebandSignal(pb.DeviceArray(view.tensor.reshape(n, 1)), sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+    y = pb.coherent_dedispersion(z, pb.DM(3.0))
+    yr, _, _ = orc.coherent_dedispersion(x[:n].reshape(n, 1), 3.0, 1e6, 1e9)
+    assert y.shape == yr.shape and np.linalg.norm(np.asarray(y) - yr) / np.linalg.norm(yr) < RTOL_L2
+    s = pb.Signal(view, sample_rate=1 * u.kHz)
+    got = np.asarray(pb.time_shift(s, 29.09))
+    ref, _, _ = orc.time_shift(x[:n], 29.09)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 4e-6
