@@ -833,3 +833,35 @@ def test_odd_length_single_series_padding(n):
     got = np.asarray(pb.time_shift(s, 29.09))
     ref, _, _ = orc.time_shift(x[:n], 29.09)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 4e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,tail,dtype,g0", [
+    (4233, (3, 2), np.complex64, 1), ((1 << 15) + 1, (1,), np.complex64, 3), (1 << 16, (4, 2), np.complex64, 1),
+    (3 << 19, (2,), np.complex64, 2), (1 << 20, (1, 2), np.complex64, 0), (100003, (2, 3), np.complex64, 1),
+    ((1 << 14) + 3, (1,), np.complex128, 1), (1 << 17, (2, 2), np.complex128, 3), (2999, (5,), np.complex128, 2),
+])
+def test_no_access_outside_the_arrays(n, tail, dtype, g0):
+    """The input is a view into a buffer of NaNs (at a sample offset that breaks 16-byte alignment for odd series
+    counts), the output a view into a buffer of sentinels: a read outside the input poisons the result, a write
+    outside the output shows (tools/fuzz_guard.py runs this over random shapes)."""
+    from pulsarbat_amd.transforms.dedispersion import _prepare
+    G = 64
+    rng = np.random.default_rng(n % 1013)
+    x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(dtype)
+    buf = np.full((G + g0 + n + G,) + tail, np.nan + 1j * np.nan, dtype=dtype)
+    buf[G + g0:G + g0 + n] = x
+    view = pb.DeviceArray.from_host(buf)[G + g0:G + g0 + n]
+    dm = 0.2 * min(1.0, n / 4096)
+    z = pb.BasebandSignal(view, sample_rate=1 * u.MHz, center_freq=1 * u.GHz)
+    yr, start, stop = orc.coherent_dedispersion(x, dm, 1e6, 1e9)
+    plan, xin, s0, s1 = _prepare(z, pb.DM(dm), None, None, "auto")
+    assert (s0, s1) == (start, stop)
+    nout = stop - start
+    obuf = pb.DeviceArray.from_host(np.full((G + nout + G,) + tail, 777.0 + 0j, dtype=dtype))
+    plan.dedisperse(xin, out=obuf[G:G + nout])
+    res = np.asarray(obuf)
+    assert np.all(res[:G] == 777.0) and np.all(res[G + nout:] == 777.0)
+    got = res[G:G + nout]
+    assert np.all(np.isfinite(got))
+    assert np.linalg.norm(got - yr) / np.linalg.norm(yr) < (5e-6 if dtype == np.complex64 else 1e-9)
