@@ -1,0 +1,5 @@
+"""One dual-polarisation channel (S = 2): the direct 3-pass variant at several lengths."""
+import sys; sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+import bench_shapes as b
+for lg in (20, 22, 24, 25, 26, 27):
+    b.run(lg, 1, 2, dm=5.0 if lg < 24 else 56.77, nchan_total=8)
