@@ -227,6 +227,12 @@ int pbh_dedisperse_stream_raw(pbh_plan* plan, const void* host_raw, size_t raw_b
                               const unsigned char* conj_mask, float scale, void* host_out,
                               int64_t* nchunk, float* ms_total);
 
+/* Conversion of a device (nsample, nseries) complex array between the two device layouts (what
+ * DeviceArray.to_series_major() / .contiguous() do; the reference has one layout, pulsarbat/core.py:59-97): one
+ * transposing pass with the pipeline's layout kernels.                                                     */
+int pbh_relayout(int device, void* hip_stream, int dtype, const void* in_dev, int in_layout, int64_t in_pitch,
+                 void* out_dev, int out_layout, int64_t out_pitch, int64_t nsample, int nseries);
+
 /* Stand-alone detection of device- or host-resident baseband data (to_intensity / to_stokes).       */
 int pbh_detect(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nsample,
                int nchan, int npol, int mode, int nscrunch, int in_loc, int out_loc);

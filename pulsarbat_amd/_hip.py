@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "trim", "fft_c2c",
+__all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "trim", "relayout", "fft_c2c",
            "chirp_function", "copy_bench"]
 
 HOST, DEVICE = 0, 1
@@ -80,6 +80,8 @@ SIGNATURES = {
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_trim": (C.c_int, []),
+    "pbh_relayout": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
+                               C.c_int64, C.c_int]),
     "pbh_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "pbh_decode": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_RawLayout), C.c_int64,
                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
@@ -194,6 +196,21 @@ def filter_plan(nsample, nseries, lo, hi, device, dtype, shared=False):
     for old in stale:
         old.close()
     return plan
+
+
+def relayout(x, out):
+    """Copy device array ``x`` into ``out`` (same shape and complex dtype), either of them C-contiguous or series-major."""
+    _require_device()
+    n = x.shape[0]
+    nser = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
+    ip = None if x.tensor.is_contiguous() else x.series_major_pitch()
+    op = None if out.tensor.is_contiguous() else out.series_major_pitch()
+    if (ip is None and not x.tensor.is_contiguous()) or (op is None and not out.tensor.is_contiguous()):
+        raise ValueError("arrays must be C-contiguous or series-major")
+    _check(lib().pbh_relayout(x.device_index, _stream_ptr(x.device_index), _dtype_code(x.dtype), C.c_void_p(x.raw_ptr()),
+                              int(ip is not None), int(ip or 0), C.c_void_p(out.raw_ptr()), int(op is not None), int(op or 0),
+                              int(n), nser))
+    return out
 
 
 def trim():

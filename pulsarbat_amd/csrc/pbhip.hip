@@ -25,6 +25,7 @@
 #define pbh_transfer PBH_FN(transfer)
 #define pbh_decode PBH_FN(decode)
 #define pbh_trim PBH_FN(trim)
+#define pbh_relayout PBH_FN(relayout)
 #define pbh_dedisperse_stream_raw PBH_FN(dedisperse_stream_raw)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
@@ -411,20 +412,21 @@ static int launch_reint_blk(const cf* work, cf* out, int64_t start, int64_t stop
 }
 
 // nvalid: input time samples that exist (the rest of the N is zero padding; N for an ordinary call)
-static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t nvalid, hipStream_t st) {
+static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t nvalid, hipStream_t st, int64_t plane = 0) {
+    if (plane <= 0) plane = N;   // elements between consecutive series of the planar side
     switch (blk_series(S, N)) {
-        case 4: return launch_deint_blk<4>(in, work, N, S, N, nvalid, st);
-        case 8: return launch_deint_blk<8>(in, work, N, S, N, nvalid, st);
-        case 16: return launch_deint_blk<16>(in, work, N, S, N, nvalid, st);
-        case 32: return launch_deint_blk<32>(in, work, N, S, N, nvalid, st);
-        case 64: return launch_deint_blk<64>(in, work, N, S, N, nvalid, st);
+        case 4: return launch_deint_blk<4>(in, work, N, S, plane, nvalid, st);
+        case 8: return launch_deint_blk<8>(in, work, N, S, plane, nvalid, st);
+        case 16: return launch_deint_blk<16>(in, work, N, S, plane, nvalid, st);
+        case 32: return launch_deint_blk<32>(in, work, N, S, plane, nvalid, st);
+        case 64: return launch_deint_blk<64>(in, work, N, S, plane, nvalid, st);
     }
     const int TN = tr_rows(S);
 #ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
-#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, N, nvalid); break;
+#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, plane, nvalid); break;
             X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
         }
@@ -433,7 +435,7 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
     }
 #endif
     hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
-                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, N, nvalid);
+                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, plane, nvalid);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
@@ -522,6 +524,31 @@ static int launch_reint_radix(int S, int P, const cf* work, cf* out, int64_t N, 
 #undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
+}
+
+int pbh_relayout(int device, void* hip_stream, int, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
+                 int out_layout, int64_t out_pitch, int64_t nsample, int nseries) {
+    if (!in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nsample <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    auto bad = [](int l) { return l != PBH_LAYOUT_SAMPLE_MAJOR && l != PBH_LAYOUT_SERIES_MAJOR; };
+    if (bad(in_layout) || bad(out_layout)) return fail(PBH_ERR_INVALID, "bad layout");
+    if ((in_layout == PBH_LAYOUT_SERIES_MAJOR && in_pitch < nsample) || (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nsample))
+        return fail(PBH_ERR_INVALID, "pitch < nsample");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const cf* in = (const cf*)in_dev;
+    cf* out = (cf*)out_dev;
+    if (in_layout == out_layout) {
+        if (in_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
+            HIPCHECK(hipMemcpyAsync(out, in, sizeof(cf) * (size_t)nsample * nseries, hipMemcpyDeviceToDevice, st));
+        } else {
+            HIPCHECK(hipMemcpy2DAsync(out, sizeof(cf) * (size_t)out_pitch, in, sizeof(cf) * (size_t)in_pitch,
+                                      sizeof(cf) * (size_t)nsample, (size_t)nseries, hipMemcpyDeviceToDevice, st));
+        }
+        return PBH_OK;
+    }
+    if (in_layout == PBH_LAYOUT_SAMPLE_MAJOR) return launch_deinterleave(in, out, nsample, nseries, nsample, st, out_pitch);
+    return launch_reinterleave(in, out, 0, nsample, nseries, in_pitch, st);
 }
 
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
@@ -839,6 +866,11 @@ static hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hi
     }
     return e;
 }
+
+// Layout conversion of a device (nsample, nseries) array (DeviceArray.to_series_major / contiguous): one transposing
+// pass with the pipeline's own layout kernels.
+int pbh_relayout(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_dev, int in_layout, int64_t in_pitch,
+                 void* out_dev, int out_layout, int64_t out_pitch, int64_t nsample, int nseries);
 
 // Plain copy between caller (host) memory and device memory through the bounce buffers above; what
 // pulsarbat_amd.DeviceArray uses for from_host() / get() so that no pageable caller memory is ever

@@ -24,6 +24,7 @@
     int P##decimate2(int, void*, int, const void*, void*, int64_t, int);                                        \
     int P##transfer(int, void*, void*, const void*, size_t, int);                                               \
     int P##trim(void);                                                                                          \
+    int P##relayout(int, void*, int, const void*, int, int64_t, void*, int, int64_t, int64_t, int);            \
     int P##decode(int, void*, const void*, size_t, int, const pbh_raw_layout_t*, int64_t, int64_t, int, int,    \
                   const unsigned char*, float, void*, int, int64_t);                                            \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
@@ -150,6 +151,12 @@ int pbh_decode(int device, void* stream, const void* raw, size_t raw_bytes, int 
                int out_layout, int64_t out_pitch) {
     return done(PBH_C64, pbh32_decode(device, stream, raw, raw_bytes, raw_loc, layout, first, nsample, nchan, npol, conj_mask,
                                       scale, out, out_layout, out_pitch));
+}
+int pbh_relayout(int device, void* stream, int dtype, const void* in, int il, int64_t ip, void* out, int ol, int64_t op, int64_t n,
+                 int nseries) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_relayout(device, stream, dtype, in, il, ip, out, ol, op, n, nseries));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_relayout(device, stream, dtype, in, il, ip, out, ol, op, n, nseries));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
 }
 int pbh_trim(void) {
     pbh32_trim();

@@ -865,3 +865,24 @@ def test_no_access_outside_the_arrays(n, tail, dtype, g0):
     got = res[G:G + nout]
     assert np.all(np.isfinite(got))
     assert np.linalg.norm(got - yr) / np.linalg.norm(yr) < (5e-6 if dtype == np.complex64 else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((1 << 16, 4, 2), np.complex64), ((100003, 3), np.complex64), ((4097, 5, 2), np.complex64),
+                                         ((1 << 15, 2, 2), np.complex128), ((777, 7), np.complex128), ((1 << 12, 200), np.complex64)])
+def test_layout_conversion(shape, dtype):
+    """DeviceArray.to_series_major runs the pipeline's de-interleave kernel (pbh_relayout); values and strides."""
+    from pulsarbat_amd import _hip
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+    d = pb.DeviceArray.from_host(x)
+    for align in (0, 5):
+        s = d.to_series_major(align_start=align)
+        assert s.series_major_pitch() is not None and tuple(s.shape) == shape
+        assert np.array_equal(np.asarray(s), x)
+        back = pb.DeviceArray.empty(shape, dtype)
+        _hip.relayout(s, back)
+        assert np.array_equal(np.asarray(back), x)
+        s2 = pb.DeviceArray.empty_series_major(shape, dtype, align_start=3)
+        _hip.relayout(s, s2)            # series-major -> series-major with another pitch / offset
+        assert np.array_equal(np.asarray(s2), x)
