@@ -177,7 +177,7 @@ class DeviceArray:
 
     def get(self):
         """Host copy as numpy."""
-        t = self._t if self._t.is_contiguous() else self._t.contiguous()
+        t = self.contiguous()._t
         if t.numel() == 0:
             return t.cpu().numpy()
         from . import _hip
