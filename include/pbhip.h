@@ -199,6 +199,7 @@ int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsa
  * elem0 + t*stride_t + chan*stride_c + pol*stride_p (strides in elements, may be negative), an element being
  * `ncomp` components (1 real, 2 complex: re, im) of `nbits` bits each, low bits first within a byte.
  *   nbits 8, code 0: two's complement (DADA, GUPPI);  code 1: offset binary, v - 128 (VDIF)
+ *   nbits 4: offset binary, v - 8 (VDIF; pass scale = 1/2.95 for the usual normalisation)
  *   nbits 2: 4-level code 0..3 -> -3.3359, -1, +1, +3.3359 (VDIF / Mark 5)
  * Output (device): float32 (ncomp 1) or complex64 (ncomp 2) array of logical shape (nsample, nchan, npol) in
  * `out_layout` (pbh_layout; out_pitch in elements for PBH_LAYOUT_SERIES_MAJOR), values times `scale`, imaginary

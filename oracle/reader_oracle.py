@@ -98,6 +98,8 @@ def unpack_general(raw, layout, first, n, nchan, npol):
         if nbits == 8:
             v = raw[base + ci]
             comp.append((v.astype(np.int16) - 128).astype(np.float32) if layout["code"] else v.view(np.int8).astype(np.float32))
+        elif nbits == 4:
+            comp.append((((raw[base + (ci >> 1)] >> (4 * (ci & 1)).astype(np.uint8)) & 15).astype(np.float32) - 8))
         else:
             comp.append(VDIF_2BIT[(raw[base + (ci >> 2)] >> (2 * (ci & 3)).astype(np.uint8)) & 3])
     return (comp[0] + 1j * comp[1]).astype(np.complex64) if nc == 2 else comp[0]

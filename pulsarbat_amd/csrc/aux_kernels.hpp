@@ -288,8 +288,9 @@ struct DecodeParams {
     int64_t blk_stride;  // bytes from one block to the next
     int64_t hdr;         // bytes from the start of a block to its payload
     int64_t e0, st_t, st_c, st_p;
-    int nbits;           // 8 or 2
-    int code;            // nbits 8: 0 two's complement, 1 offset binary (v - 128); nbits 2: 4-level VDIF table
+    int nbits;           // 8, 4 or 2
+    int code;            // nbits 8: 0 two's complement, 1 offset binary (v - 128); nbits 4: offset binary (v - 8);
+                         // nbits 2: 4-level VDIF table
     int lanes_t;         // consecutive lanes read consecutive time samples (else consecutive series)
     int ls;              // log2 of the series per tile
     int npol_shift;      // log2(npol), or -1
@@ -355,8 +356,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const int64_t ci = e * NC + k;
-                raw[k][j] = NBITS == 8 ? pay[ci] : pay[ci >> 2];
-                shift[k][j] = 2 * (int)(ci & 3);
+                raw[k][j] = NBITS == 8 ? pay[ci] : (NBITS == 4 ? pay[ci >> 1] : pay[ci >> 2]);
+                shift[k][j] = NBITS == 4 ? 4 * (int)(ci & 1) : 2 * (int)(ci & 3);
             }
         }
     }
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
             if (NBITS == 8) {
                 const int v = PAIR ? (int)((raw[0][j] >> (8 * k)) & 0xFF) : (int)raw[k][j];
                 val = q.code ? (float)(v - 128) : (float)(signed char)v;
+            } else if (NBITS == 4) {
+                val = (float)((int)((raw[k][j] >> shift[k][j]) & 15) - 8);   // offset binary (VDIF)
             } else {
                 const int c2 = (raw[k][j] >> shift[k][j]) & 3;
                 const float mag = (c2 == 0 || c2 == 3) ? 3.3359f : 1.0f;   // optimal 4-level thresholds (VDIF / Mark 5)

@@ -896,8 +896,8 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
     if (!L) return fail(PBH_ERR_INVALID, "NULL argument");
     if (nsample <= 0 || first < 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "bad dimensions");
     if (L->ncomp != 1 && L->ncomp != 2) return fail(PBH_ERR_INVALID, "ncomp must be 1 or 2");
-    if (!((L->nbits == 8 && (L->code == 0 || L->code == 1)) || (L->nbits == 2 && L->code == 0)))
-        return fail(PBH_ERR_UNSUPPORTED, "payload coding: 8 bits (code 0/1) or 2 bits");
+    if (!((L->nbits == 8 && (L->code == 0 || L->code == 1)) || ((L->nbits == 2 || L->nbits == 4) && L->code == 0)))
+        return fail(PBH_ERR_UNSUPPORTED, "payload coding: 8 bits (code 0/1), 4 bits or 2 bits");
     if (L->blk_samples <= 0 || L->blk_stride < 0 || L->hdr_bytes < 0) return fail(PBH_ERR_INVALID, "bad block geometry");
     if ((int64_t)nchan * npol > 65535LL * 64) return fail(PBH_ERR_UNSUPPORTED, "too many series");
     const int64_t b0 = first / L->blk_samples, b1 = (first + nsample - 1) / L->blk_samples;
@@ -989,8 +989,10 @@ static int decode_launch(const unsigned char* draw, int64_t skip, const pbh_raw_
             hipLaunchKernelGGL((k_decode<NC, NB, false>), grid, dim3(256), 0, st, q);         \
     } while (0)
     if (L->ncomp == 2 && L->nbits == 8) LAUNCH(2, 8);
+    else if (L->ncomp == 2 && L->nbits == 4) LAUNCH(2, 4);
     else if (L->ncomp == 2) LAUNCH(2, 2);
     else if (L->nbits == 8) LAUNCH(1, 8);
+    else if (L->nbits == 4) LAUNCH(1, 4);
     else LAUNCH(1, 2);
 #undef LAUNCH
     HIPCHECK(hipGetLastError());

@@ -105,7 +105,7 @@ class BasebandReader(BaseReader):
         lay = raw.layout()
         lay.update(elem0=elem0, stride_c=strides[0], stride_p=strides[1])
         conj = self._conj_mask(shape1) if raw.complex_data else None
-        return _hip.decode(buf, lay, first, n * ncomp_real_factor, shape1[0], shape1[1], conj=conj,
+        return _hip.decode(buf, lay, first, n * ncomp_real_factor, shape1[0], shape1[1], conj=conj, scale=raw.scale,
                            series_major=self._series_major and raw.complex_data, device=self._device)
 
     def _finish(self, z):

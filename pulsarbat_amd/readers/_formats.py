@@ -49,6 +49,7 @@ class RawStream:
     blocks: list = field(default_factory=list, repr=False)   # (file index, byte position of the payload)
     files: list = field(default_factory=list, repr=False)
     gather: object = field(default=None, repr=False)          # optional per-block reader (VDIF frame sets)
+    scale: float = 1.0           # factor applied to the unpacked integers (VDIF 4- / 8-bit normalisation)
 
     def layout(self):
         return dict(nbits=self.nbits, ncomp=2 if self.complex_data else 1, code=self.code, blk_samples=self.blk_samples,
@@ -264,8 +265,8 @@ def _open_vdif(files):
             pos += frame_bytes
     threads = sorted(sets[order[0]])
     order = [k for k in order if sorted(sets[k]) == threads]   # complete frame sets only
-    if bps not in (2, 8):
-        raise ValueError(f"VDIF: {bps}-bit samples are not supported (2 or 8)")
+    if bps not in (2, 4, 8):
+        raise ValueError(f"VDIF: {bps}-bit samples are not supported (2, 4 or 8)")
     pay = frame_bytes - hbytes
     ncomp = 2 if complex_data else 1
     per_frame = pay * 8 // (bps * ncomp * nchan)
@@ -286,7 +287,10 @@ def _open_vdif(files):
                      complex_data=complex_data, nbits=bps, code=1 if bps == 8 else 0,
                      sample_rate=u.Quantity(rate_hz, u.Hz), start_time=t0, blk_samples=per_frame,
                      blk_bytes=pay * len(threads), elem0=0, stride_t=nchan, stride_1=per_frame * nchan, stride_2=1,
-                     blocks=blocks, files=files, gather=_vdif_gather)
+                     blocks=blocks, files=files, gather=_vdif_gather,
+                     # multi-bit VDIF samples are scaled to the 2-bit convention (low level = 1), as `baseband` does:
+                     # 4 bits: (v - 8) / 2.95, 8 bits: (v - 128) / 35.5
+                     scale={2: 1.0, 4: 1.0 / 2.95, 8: 2.0 / 71.0}[bps])
 
 
 def open_raw(name, format=None):

@@ -304,7 +304,7 @@ def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n):
     mask = reader._conj_mask(shape1)
     if mask is not None:
         mask = np.asarray(mask).reshape(plan.nchan, plan.npol)
-    y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask)
+    y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask, scale=reader._raw.scale)
     y = y.reshape((len(y),) + reader.sample_shape)
     return type(head).like(head, y, **_advance(head, start)), ms
 

@@ -246,7 +246,7 @@ class TestDeviceDecode:
         want = np.flip(ro.dada_samples(DATA / "stokes_ef.dada"), axis=-1).transpose(0, 2, 1)
         assert np.array_equal(np.asarray(r.read(3, 13)), want[3:16])
 
-    @pytest.mark.parametrize("nbits,ncomp,code", [(8, 2, 0), (8, 2, 1), (8, 1, 0), (2, 1, 0), (2, 2, 0)])
+    @pytest.mark.parametrize("nbits,ncomp,code", [(8, 2, 0), (8, 2, 1), (8, 1, 0), (2, 1, 0), (2, 2, 0), (4, 1, 0), (4, 2, 0)])
     @pytest.mark.parametrize("series_major", [False, True])
     def test_synthetic_layouts(self, nbits, ncomp, code, series_major):
         """Random bytes through blocked, headered, strided and flipped layouts: bit-exact against the numpy
@@ -286,7 +286,7 @@ class TestDeviceDecode:
         with pytest.raises(errors):
             _hip.decode(raw, dict(lay, stride_t=3), 0, 150, 2, 1)   # a block's samples overrun into the next block
         with pytest.raises(errors):
-            _hip.decode(raw, dict(lay, nbits=4), 0, 10, 2, 1)
+            _hip.decode(raw, dict(lay, nbits=3), 0, 10, 2, 1)
 
 
 # ---- streaming straight from the payload bytes (pbh_dedisperse_stream_raw) -----------------------------------

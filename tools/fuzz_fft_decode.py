@@ -41,7 +41,7 @@ while time.time() < t_end:
         print(f"FFT BAD n={n} batch={batch} {np.dtype(dtype).name} inverse={inv}: {err:.3e}", flush=True)
     # ---- decode ----
     nchan, npol = int(rng.integers(1, 40)), int(rng.integers(1, 5))
-    nbits = int(rng.choice([8, 8, 2]))
+    nbits = int(rng.choice([8, 8, 2, 4]))
     ncomp = int(rng.integers(1, 3))
     code = int(rng.integers(0, 2)) if nbits == 8 else 0
     per = 4 // ncomp if nbits == 2 else 1          # elements per byte (2-bit) -- keep block payloads whole bytes
