@@ -16,7 +16,7 @@ def timed(fn, reps=5):
 for nchan, npol in ((1, 2), (4, 2), (1, 1)):
     n = (1 << 27) // (nchan * npol)
     x = pb.DeviceArray(torch.view_as_complex(torch.randn((n, nchan, npol, 2), device="cuda")))
-    for nper in (32, 256, 1024, 2048, 4096, 8192, 16384, 1 << 16):
+    for nper in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 1 << 16):
         ms = timed(lambda: _hip.stft(x, nper))
         y = _hip.stft(x, nper)
         ms2 = timed(lambda: _hip.stft(y, nper, inverse=True))
