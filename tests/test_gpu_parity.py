@@ -844,7 +844,7 @@ def test_odd_length_single_series_padding(n):
 def test_no_access_outside_the_arrays(n, tail, dtype, g0):
     """The input is a view into a buffer of NaNs (at a sample offset that breaks 16-byte alignment for odd series
     counts), the output a view into a buffer of sentinels: a read outside the input poisons the result, a write
-    outside the output shows (tools/fuzz_guard.py runs this over random shapes)."""
+    outside the output shows (tests/tools/fuzz_guard.py runs this over random shapes)."""
     from pulsarbat_amd.transforms.dedispersion import _prepare
     G = 64
     rng = np.random.default_rng(n % 1013)
