@@ -239,8 +239,14 @@ class TestHotPathWithoutGpu:
     def test_product_does_not_import_oracle(self):
         import os, re
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for dirpath, _, files in os.walk(os.path.join(root, "pulsarbat_amd")):
-            for f in files:
-                if f.endswith(".py"):
-                    src = open(os.path.join(dirpath, f)).read()
-                    assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+        # the package and the measurement scripts; (bench.py imports it inside its CPU-baseline leg only, below)
+        for sub in ("pulsarbat_amd", "tools"):
+            for dirpath, _, files in os.walk(os.path.join(root, sub)):
+                for f in files:
+                    if f.endswith(".py"):
+                        src = open(os.path.join(dirpath, f)).read()
+                        assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+        bench = open(os.path.join(root, "bench.py")).read()
+        uses = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle", bench, re.M)]
+        enclosing = bench[:uses[0]].rsplit("\ndef ", 1)[-1]     # text from the last "def" before the import
+        assert len(uses) == 1 and enclosing.startswith("cpu_baseline(")
