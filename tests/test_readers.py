@@ -342,3 +342,21 @@ class TestRawStream:
         with pytest.raises((ValueError, _hip.HipError)):
             plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk + 1)      # one sample beyond the buffer
         plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk)
+
+
+def test_reader_oracle_against_frozen_vectors():
+    """tests/golden/readers_expected.npz (made by tests/golden/make_golden_readers.py) pins the oracle's unpacking of
+    the reference's data files."""
+    g = np.load(Path(__file__).parent / "golden" / "readers_expected.npz")
+    x = ro.dada_samples(DATA / "sample.dada")
+    assert np.array_equal(x[:32], g["dada_head"]) and np.array_equal(x[-32:], g["dada_tail"])
+    x = ro.vdif_samples(DATA / "sample.vdif")
+    assert np.array_equal(x[:64], g["vdif_head"]) and np.array_equal(x[-64:], g["vdif_tail"])
+    x = ro.guppi_samples(GUPPI).transpose(0, 2, 1)
+    assert np.array_equal(x[:32], g["guppi_head"]) and np.array_equal(x[8192 - 16:8192 + 16], g["guppi_mid"])
+    assert np.array_equal(x[-32:], g["guppi_tail"])
+    x = np.flip(ro.dada_samples(DATA / "stokes_ef.dada"), axis=-1).transpose(0, 2, 1)
+    assert np.array_equal(x[0], g["stokes_first"]) and np.array_equal(x[-1], g["stokes_last"])
+    # sanity of the data themselves: 2-bit VDIF samples take the four levels, 8-bit DADA samples are integers
+    assert set(np.unique(g["vdif_head"])) <= {np.float32(-3.3359), np.float32(-1), np.float32(1), np.float32(3.3359)}
+    assert np.all(g["dada_head"].real == np.round(g["dada_head"].real))
