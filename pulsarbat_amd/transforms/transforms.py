@@ -114,9 +114,10 @@ def freq_shift(z, /, shift):
     S = ft.size
     xm = DeviceArray(x.tensor.reshape(N, S).clone())  # the mixer works in place: keep the caller's data
     _hip.mix(xm, ft)
-    plan = _hip.filter_plan(N, S, 0, N, xm.device_index, xm.dtype)
-    plan.chirp_special(ft * N, 1)
-    y = plan.dedisperse(DeviceArray(xm.tensor.reshape(N, S, 1)))
+    same = bool(np.all(ft == ft[0]))   # one shift for every series: a single shared band mask
+    plan = _hip.filter_plan(N, S, 0, N, xm.device_index, xm.dtype, shared=same)
+    plan.chirp_special((ft[:1] if same else ft) * N, 1)
+    y = plan.dedisperse(DeviceArray(xm.tensor.reshape((N, 1, S) if same else (N, S, 1))))
     out = _from_device(DeviceArray(y.tensor.reshape(N, S)), on_dev, False, dt, (N,) + tuple(z.sample_shape))
     return type(z).like(z, out)
 
