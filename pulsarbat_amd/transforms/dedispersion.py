@@ -324,7 +324,13 @@ def incoherent_dedispersion(z, DM, /, *, ref_freq=None):
     crop_before = -min(0, delays[0], delays[-1])
     delays = delays + crop_before
     N = len(z) - max(delays)
-    if isinstance(z.data, DeviceArray):
+    if isinstance(z.data, DeviceArray) and not z.data.tensor.is_contiguous() and z.data.series_major_pitch() is not None:
+        # series-major (time fastest): every channel is a contiguous run -- one shifted copy per channel instead of
+        # the line-granular gather of the sample-major layout
+        x = DeviceArray.empty_series_major((max(N, 0),) + tuple(z.sample_shape), z.dtype, device=z.data.device_index)
+        for i, j in enumerate(delays):
+            x.tensor[:, i].copy_(z.data.tensor[int(j):int(j) + max(N, 0), i])
+    elif isinstance(z.data, DeviceArray):
         x = _hip.incoherent(z.data, delays, max(N, 0))
     else:
         x = np.stack([z.data[j:j + N, i] for i, j in enumerate(delays)], axis=1)

@@ -72,3 +72,17 @@ def test_pol_reversibility_device(pol_type, dtype):
     # Stokes from either basis agree (reference tests/test_polarization.py:50-60)
     s1, s2 = zd.to_linear().to_stokes(), zd.to_circular().to_stokes()
     assert np.allclose(np.asarray(s1), np.asarray(s2), atol=10 * tol)
+
+
+@pytest.mark.gpu
+def test_incoherent_series_major_arrays():
+    """Series-major device arrays: one shifted contiguous copy per channel; same values, layout kept."""
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((1 << 16, 6, 2)) + 1j * rng.standard_normal((1 << 16, 6, 2))).astype(np.complex64)
+    z = pb.DualPolarizationSignal(x, sample_rate=1 * u.MHz, center_freq=400 * u.MHz, pol_type="linear",
+                                  start_time=pb.Time(56000.0, format="mjd"))
+    a = pb.incoherent_dedispersion(z.to_device(), pb.DM(3.0))
+    zs = type(z).like(z, z.to_device().data.to_series_major())
+    b = pb.incoherent_dedispersion(zs, pb.DM(3.0))
+    assert b.data.series_major_pitch() is not None and a.shape == b.shape
+    assert np.array_equal(np.asarray(a), np.asarray(b)) and a.start_time.isclose(b.start_time)
