@@ -25,6 +25,7 @@
 #ifndef PBHIP_H
 #define PBHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -53,3 +53,14 @@ def test_argument_validation_without_gpu():
     if lib.pbh_device_count() == 0:
         assert lib.pbh_plan_create(ctypes.byref(h), 0, 1024, 1, 1, 0, 0, 1024) == -1
         assert b"not present" in lib.pbh_last_error()
+
+
+def test_header_is_self_contained_c_and_cpp():
+    """include/pbhip.h compiles on its own as C99 and as C++ (what a cgo / JNI / ctypes-generator consumer needs)."""
+    import shutil, subprocess
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pbhip.h")
+    for cc, args in (("gcc", ["-std=c99", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        r = subprocess.run([cc, "-Wall", "-Werror", "-fsyntax-only"] + args + [header], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
