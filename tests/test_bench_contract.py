@@ -1,0 +1,33 @@
+"""bench.py prints ONE JSON line with the fields the driver and the judge read."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-series"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["unit"] == "Msamples/s" and j["dtype"] == "c64" and j["data"] == "synthetic" and j["scaling"] == "weak"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value is the whole-job rate of the timed region
+    nsamp = j["config"]["nsample"] * j["config"]["nchan_per_gpu"] * j["config"]["npol"]
+    assert abs(j["value"] - nsamp / j["ms_per_step"] / 1e3) / j["value"] < 1e-6
+    roof = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0.3 < roof["frac"] < 1.0
