@@ -1620,7 +1620,7 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
     static thread_local int64_t* d = nullptr;
     static thread_local int d_cap = 0, d_dev = -1;
     static thread_local hipStream_t d_stream = nullptr;
-    if (d && d_stream != st) HIPCHECK(hipStreamSynchronize(d_stream));   // the previous user may still be reading
+    if (d && d_stream != st) HIPCHECK(hipDeviceSynchronize());   // the previous user (another stream, possibly gone by now) may still be reading
     if (!d || d_cap < nchan || d_dev != device) {
         if (d) {
             HIPCHECK(hipDeviceSynchronize());
