@@ -108,6 +108,11 @@ int pbh_chirp_generate(pbh_plan* plan, double coeff_hz, double dt_s,
                        const double* chan_freq_hz /* [nchan] */, double ref_freq_hz);
 /* User-supplied chirp= of coherent_dedispersion (dedispersion.py:121-124): (nsample, nchan) c64. */
 int pbh_chirp_upload(pbh_plan* plan, const void* chirp_c64, int loc);
+/* Same with the chirp's dtype stated: PBH_C64, or PBH_C128 for a complex128 plan.  The reference multiplies by
+ * whatever array it is handed (`fft(z.data) * chirp`, dedispersion.py:124-125), so a complex128 chirp keeps its
+ * precision there; the host promotes the data dtype the way numpy's product would.  A chirp that differs between
+ * polarisations is a plan over nchan*npol "channels" with npol = 1 (the host reshapes).                       */
+int pbh_chirp_upload_as(pbh_plan* plan, const void* chirp, int chirp_dtype, int loc);
 /* The plan's chirp in natural order, (nsample, nchan) c64: what chirp_from_signal returns.       */
 int pbh_chirp_download(pbh_plan* plan, void* chirp_c64, int loc);
 /* Stand-alone DispersionMeasure.chirp_function (dedispersion.py:44-57): one channel, (nsample,). */
@@ -170,6 +175,35 @@ int pbh_dedisperse(pbh_plan* plan, const void* in_c64, void* out_c64, int in_loc
 typedef enum { PBH_LAYOUT_SAMPLE_MAJOR = 0, PBH_LAYOUT_SERIES_MAJOR = 1 } pbh_layout;
 int pbh_dedisperse_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
                           int out_layout, int64_t out_pitch);
+/* Multi-GPU: the same transform with the (nout, nchan, npol) result written as a channel slice of a wider
+ * sample-major array: row t of the result goes to out_dev[t*out_row_elems + out_col_offset + (chan*npol + pol)].
+ * A rank of a channel-sharded job (reference: Dask chunks over the non-time axes, core.py:332-345) passes the
+ * full-band block -- its own, or a peer GPU's mapped with pbh_node_import -- with out_row_elems =
+ * nchan_total*npol and out_col_offset = first_channel*npol, so the gather of Signal.compute()
+ * (core.py:298-309) is done by the pipeline's last kernel.  Device-resident, C-contiguous input;
+ * asynchronous on the plan's stream.  Fastest when nchan*npol is a power of two <= 128 and the
+ * offset / row length are even (16-byte stores); every other geometry is served through one extra pass. */
+int pbh_dedisperse_slice(pbh_plan* plan, const void* in_dev, void* out_dev, int64_t out_row_elems,
+                         int64_t out_col_offset);
+
+/* Sharing a device buffer between the ranks of one node (one process per GPU).  The destination rank
+ * allocates with pbh_node_alloc (a whole device allocation, hence exportable), exports a 64-byte handle,
+ * ships it to its peers by any host channel (the Python host uses torch.distributed), and each peer maps
+ * it with pbh_node_import (peer access over xGMI is enabled by the mapping) and writes into it with
+ * pbh_dedisperse_slice.  The exporter must keep the buffer alive until every importer has called
+ * pbh_node_release; a host-side barrier after the writers' streams have drained makes the data visible
+ * to the owner.  Replaces the reference's in-process gather of chunk results (core.py:298-309).          */
+/* pbh_place: 2-D copy between sample-major device arrays (nrow rows of ncol complex elements, row pitches in
+ * elements) -- the push of a rank's channel slice into a peer's full-band block in the all-gather form.       */
+int pbh_place(int device, void* hip_stream, int dtype, const void* src_dev, int64_t src_row_elems, void* dst_dev,
+              int64_t dst_row_elems, int64_t nrow, int64_t ncol);
+typedef struct { unsigned char bytes[64]; } pbh_ipc_handle_t;
+int pbh_node_alloc(int device, size_t bytes, void** dev_ptr);
+int pbh_node_free(int device, void* dev_ptr);
+int pbh_node_export(int device, void* dev_ptr, pbh_ipc_handle_t* handle);
+int pbh_node_import(int device, const pbh_ipc_handle_t* handle, void** dev_ptr);
+int pbh_node_release(int device, void* dev_ptr);
+
 /* pbh_dedisperse_detect (below) for a device-resident input with a stated layout; out is the C-contiguous
  * detected array.  A series-major input needs the fused tail (nscrunch % 64 == 0): 4 kernels.            */
 int pbh_dedisperse_detect_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch,
@@ -201,7 +235,7 @@ int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsa
  * `ncomp` components (1 real, 2 complex: re, im) of `nbits` bits each, low bits first within a byte.
  *   nbits 8, code 0: two's complement (DADA, GUPPI);  code 1: offset binary, v - 128 (VDIF)
  *   nbits 4: offset binary, v - 8 (VDIF; pass scale = 1/2.95 for the usual normalisation)
- *   nbits 2: 4-level code 0..3 -> -3.3359, -1, +1, +3.3359 (VDIF / Mark 5)
+ *   nbits 2: 4-level code 0..3 -> -3.316505, -1, +1, +3.316505 (baseband's OPTIMAL_2BIT_HIGH)
  * Output (device): float32 (ncomp 1) or complex64 (ncomp 2) array of logical shape (nsample, nchan, npol) in
  * `out_layout` (pbh_layout; out_pitch in elements for PBH_LAYOUT_SERIES_MAJOR), values times `scale`, imaginary
  * part negated for the series whose entry in conj_mask (host, nchan*npol bytes, may be NULL) is non-zero.

@@ -15,7 +15,7 @@ decoded VALUES are pinned by the format definitions only.
 
 import numpy as np
 
-VDIF_2BIT = np.array([-3.3359, -1.0, 1.0, 3.3359], np.float32)
+VDIF_2BIT = np.array([-3.316505, -1.0, 1.0, 3.316505], np.float32)   # baseband.base.encoding.OPTIMAL_2BIT_HIGH
 
 
 def dada_samples(path):

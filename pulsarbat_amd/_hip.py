@@ -68,6 +68,7 @@ SIGNATURES = {
     "pbh_plan_info": (C.c_int, [C.c_void_p, C.POINTER(_PlanInfo)]),
     "pbh_chirp_generate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double]),
     "pbh_chirp_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pbh_chirp_upload_as": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pbh_chirp_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "pbh_chirp_special": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pbh_mix": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -86,6 +87,13 @@ SIGNATURES = {
     "pbh_decode": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_RawLayout), C.c_int64,
                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
+    "pbh_dedisperse_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "pbh_place": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "pbh_node_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pbh_node_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "pbh_node_export": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "pbh_node_import": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pbh_node_release": (C.c_int, [C.c_int, C.c_void_p]),
     "pbh_dedisperse_detect_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -256,12 +264,13 @@ class Plan:
             _check(lib().pbh_plan_set_variant(self._h, VARIANTS[variant]))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        h = getattr(self, "_h", None)
+        self._h = None
+        if h is not None and h.value:
             try:
-                lib().pbh_plan_destroy(self._h)
+                lib().pbh_plan_destroy(h)
             except Exception:   # interpreter shutdown: module globals may be gone, the process frees the memory
                 pass
-            self._h = C.c_void_p()
 
     __del__ = close
 
@@ -302,11 +311,14 @@ class Plan:
         _check(lib().pbh_chirp_special(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), int(mode)))
 
     def chirp_upload(self, chirp):
+        """chirp: (nsample, nchan) complex64, or complex128 for a complex128 plan; numpy or DeviceArray."""
         self._sync_stream()
-        if tuple(chirp.shape) != (self.nsample, self.nchan) or chirp.dtype != np.complex64:
-            raise ValueError(f"chirp must be complex64 with shape {(self.nsample, self.nchan)}")
+        if tuple(chirp.shape) != (self.nsample, self.nchan) or np.dtype(chirp.dtype) not in DTYPES:
+            raise ValueError(f"chirp must be complex64 / complex128 with shape {(self.nsample, self.nchan)}")
+        if np.dtype(chirp.dtype) == np.complex128 and self.dtype != np.complex128:
+            raise TypeError("a complex128 chirp needs a complex128 plan")
         ptr, loc = _ptr_loc(chirp)
-        _check(lib().pbh_chirp_upload(self._h, ptr, loc))
+        _check(lib().pbh_chirp_upload_as(self._h, ptr, DTYPES[np.dtype(chirp.dtype)], loc))
 
     def chirp_download(self, out=None):
         self._sync_stream()
@@ -375,6 +387,19 @@ class Plan:
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse(self._h, pin, pout, lin, lout))
         return out
+
+    def dedisperse_slice(self, x, out_ptr, row_elems, col_offset):
+        """Dedisperse device array ``x`` and write the ``(nout, nchan, npol)`` result as columns
+        ``[col_offset, col_offset + nchan*npol)`` of the sample-major array at device pointer ``out_ptr`` whose rows
+        are ``row_elems`` elements long -- this rank's channel slice of a full-band block, possibly on a peer GPU
+        (``pbh_dedisperse_slice``).  Asynchronous on the current stream."""
+        from .device import DeviceArray
+        if not isinstance(x, DeviceArray):
+            raise TypeError("dedisperse_slice takes a device-resident input")
+        self._check_in(x)
+        self._sync_stream()
+        _check(lib().pbh_dedisperse_slice(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(int(out_ptr)), int(row_elems),
+                                          int(col_offset)))
 
     def dedisperse_detect(self, x, nscrunch=1, mode="I", out=None):
         from .device import DeviceArray
@@ -475,7 +500,9 @@ def detect(x, mode="intensity", nscrunch=1):
     else:
         x = np.ascontiguousarray(x)
         out = np.empty(oshape, dtype=rdt)
-        dev, stream = 0, C.c_void_p(0)
+        import torch
+        dev = torch.cuda.current_device()   # host data: the process's current GPU (one process per GPU)
+        stream = _stream_ptr(dev)
     pin, lin = _ptr_loc(x)
     pout, lout = _ptr_loc(out)
     _check(lib().pbh_detect(dev, stream, code, pin, pout, int(n), int(nchan), npol, m, int(nscrunch), lin, lout))

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
 
 // natural (N, nchan) complex64 (the reference's chirp dtype) <-> plan order [chan][k1][k2] in the
 // plan's precision; `to_plan` selects the direction.
-__global__ __launch_bounds__(256) void k_chirp_reorder(const float2* __restrict__ nat_in, float2* __restrict__ nat_out,
+// (TNAT: element type of the natural-order side -- float2 for the reference's complex64 chirps, double2 for a
+//  complex128 chirp handed to the float64 build, which the reference would also keep at that precision)
+template <typename TNAT>
+__global__ __launch_bounds__(256) void k_chirp_reorder(const TNAT* __restrict__ nat_in, TNAT* __restrict__ nat_out,
                                                        const cf* __restrict__ plan_in, cf* __restrict__ plan_out,
                                                        int64_t N, int N1, int N2, int nchan, real scale,
                                                        int to_plan, int perm_w, int P) {
@@ -75,11 +78,14 @@ __global__ __launch_bounds__(256) void k_chirp_reorder(const float2* __restrict_
         const int64_t k = row_k1(r, P, N1) + (int64_t)N1 * k2;
         const int64_t nat = k * nchan + chan;
         if (to_plan) {
-            const float2 v = nat_in[nat];
+            const TNAT v = nat_in[nat];
             plan_out[d] = make_cf((real)v.x * scale, (real)v.y * scale);
         } else {
             const cf v = plan_in[d];
-            nat_out[nat] = make_float2((float)(v.x * scale), (float)(v.y * scale));
+            TNAT o;
+            o.x = (decltype(o.x))(v.x * scale);
+            o.y = (decltype(o.y))(v.y * scale);
+            nat_out[nat] = o;
         }
     }
 }
@@ -110,9 +116,11 @@ __global__ __launch_bounds__(256) void k_deinterleave(const cf* __restrict__ in,
 }
 
 // planar [s][t] -> (stop-start, S) interleaved, keeping t in [start, stop)
+// (opitch: elements between consecutive output rows; S for a compact output, more when the rows are a
+//  channel slice of a wider array -- the multi-GPU gather writes a rank's channels into the full-band block)
 __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in, cf* __restrict__ out,
                                                       int64_t start, int64_t stop, int S, int TN,
-                                                      int64_t plane) {
+                                                      int64_t plane, int64_t opitch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
@@ -125,7 +133,20 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
     __syncthreads();
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
         int n = e / S, s = e - n * S;
-        out[(t0 - start) * S + e] = lds[n * (S + 1) + s];
+        out[(t0 - start + n) * opitch + s] = lds[n * (S + 1) + s];
+    }
+}
+
+// (nrow, ncol) block with row pitch ipitch -> rows of another array with row pitch opitch (elements of T): the placing
+// pass of the sliced output, and the push of a rank's channel slice into a peer GPU's full-band block
+template <typename T>
+__global__ __launch_bounds__(256) void k_place(const T* __restrict__ in, int64_t ipitch, T* __restrict__ out, int64_t opitch,
+                                               int64_t nrow, int ncol) {
+    const int64_t total = nrow * ncol;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = e / ncol;
+        const int c = (int)(e - t * ncol);
+        out[t * opitch + c] = in[t * ipitch + c];
     }
 }
 
@@ -375,7 +396,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
                 val = (float)((int)((raw[k][j] >> shift[k][j]) & 15) - 8);   // offset binary (VDIF)
             } else {
                 const int c2 = (raw[k][j] >> shift[k][j]) & 3;
-                const float mag = (c2 == 0 || c2 == 3) ? 3.3359f : 1.0f;   // optimal 4-level thresholds (VDIF / Mark 5)
+                // high level of the 4-level code: baseband's OPTIMAL_2BIT_HIGH = 3.316505 (baseband/base/encoding.py: the mean of
+                // the samples beyond 1 sigma over the mean of those within, for a normal distribution) -- the reference
+                // reads VDIF through baseband; mark5access would use 3.3359
+                const float mag = (c2 == 0 || c2 == 3) ? 3.316505f : 1.0f;
                 val = (c2 & 2) ? mag : -mag;
             }
             lds[k][tt * pitch + ss] = val;   // (clamped lanes fill their own, unused, slot)
@@ -533,9 +557,9 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
 }
 
 // planar [s][t] -> (stop-start, S); the tail tile is handled by the generic kernel
-template <int S>
+template <int S, bool PITCHED = false>
 __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
-                                                         int64_t start, int64_t plane) {
+                                                         int64_t start, int64_t plane, int64_t opitch) {
     constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;
     __shared__ cf lds[S * LD];
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
@@ -569,7 +593,10 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
             x = lds[s * LD + n];
             y = lds[(s + 1) * LD + n];
         }
-        dst[threadIdx.x + 256 * j] = make_float4(x.x, x.y, y.x, y.y);
+        if constexpr (PITCHED)   // rows are a slice of a wider array (S >= 2, opitch and the base even: 16-byte vectors)
+            *reinterpret_cast<float4*>(out + (t0 - start + n) * opitch + s) = make_float4(x.x, x.y, y.x, y.y);
+        else
+            dst[threadIdx.x + 256 * j] = make_float4(x.x, x.y, y.x, y.y);
     }
 }
 

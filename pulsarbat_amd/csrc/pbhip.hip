@@ -14,6 +14,7 @@
 #define pbh_plan_info PBH_FN(plan_info)
 #define pbh_chirp_generate PBH_FN(chirp_generate)
 #define pbh_chirp_upload PBH_FN(chirp_upload)
+#define pbh_chirp_upload_as PBH_FN(chirp_upload_as)
 #define pbh_chirp_download PBH_FN(chirp_download)
 #define pbh_chirp_function PBH_FN(chirp_function)
 #define pbh_chirp_special PBH_FN(chirp_special)
@@ -29,6 +30,8 @@
 #define pbh_dedisperse_stream_raw PBH_FN(dedisperse_stream_raw)
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
+#define pbh_dedisperse_slice PBH_FN(dedisperse_slice)
+#define pbh_place PBH_FN(place)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
@@ -112,6 +115,8 @@ static int64_t convolution_length(int64_t x) {
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
+constexpr size_t kCounterBytes = 4096;   // tile hand-out counters of the persistent kernels, behind the stage twiddle table
+constexpr int kCounters = (int)(kCounterBytes / sizeof(unsigned));
 struct Step {
     const char* name;
     std::function<int(hipStream_t)> launch;
@@ -191,13 +196,17 @@ template <typename K, typename P>
 static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads, hipStream_t st,
                               size_t lds = lds_tile_bytes<true>() /* 132 KiB: tile + 1 pad slot per 32 */,
                               unsigned grid_y = 1) {
-    static thread_local const void* configured[128];
+    // (the attribute belongs to the (kernel, device) pair: remembered per device)
+    struct Conf { const void* fn; int dev; };
+    static thread_local Conf configured[256];
     static thread_local int nconf = 0;
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
     bool seen = false;
-    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
+    for (int i = 0; i < nconf; ++i) seen |= (configured[i].fn == (const void*)kernel && configured[i].dev == dev);
     if (!seen) {
         HIPCHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (nconf < 128) configured[nconf++] = (const void*)kernel;
+        if (nconf < 256) configured[nconf++] = Conf{(const void*)kernel, dev};
     }
     if (tiles <= 0 || tiles > 0x7fffffffLL) return fail(PBH_ERR_INVALID, "tile count out of range");
     hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, grid_y), dim3(threads), lds, st, prm);
@@ -346,6 +355,10 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
 }
 
+static int depth_mode() {
+    static const int m = [] { const char* e = getenv("PBH_DEPTH"); return e ? atoi(e) : 0; }();
+    return m;
+}
 #ifndef PBH_F64
 // PBH_ROW_PHASE=0 keeps the complex64-chirp row kernel for generated chirps too (A/B runs)
 static bool row_phase_enabled() {
@@ -440,9 +453,14 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
     return PBH_OK;
 }
 
+// opitch: elements between output rows (0 = compact, S); pitched rows (a channel slice of a wider array) are
+// written by the power-of-two row transposes and the generic kernel only -- slice_fast_ok()
 static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane,
-                               hipStream_t st) {
+                               hipStream_t st, int64_t opitch = 0) {
     if (stop <= start) return PBH_OK;
+    const bool pitched = opitch > 0 && opitch != S;
+    if (!pitched) opitch = S;
+    if (!pitched)
     switch (blk_series(S, plane)) {
         case 4: return launch_reint_blk<4>(work, out, start, stop, S, plane, st);
         case 8: return launch_reint_blk<8>(work, out, start, stop, S, plane, st);
@@ -453,11 +471,12 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     const int TN = tr_rows(S);
     int64_t done = 0;
 #ifndef PBH_F64
-    if ((S & (S - 1)) == 0 && S <= 128) {
+    if ((S & (S - 1)) == 0 && S <= 128 && !(pitched && (S < 2 || (opitch & 1) || (reinterpret_cast<uintptr_t>(out) & 15)))) {
         const int64_t full = (stop - start) / TN;
         if (full > 0) {
             switch (S) {
-#define X(s) case s: hipLaunchKernelGGL(k_reinterleave_p2<s>, dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane); break;
+#define X(s) case s: if (pitched) hipLaunchKernelGGL((k_reinterleave_p2<s, true>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch); \
+                     else hipLaunchKernelGGL((k_reinterleave_p2<s, false>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch); break;
                 X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
             }
@@ -469,7 +488,7 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     if (start + done < stop) {  // tail (or everything, for other S) through the generic kernel
         const int64_t s2 = start + done;
         hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - s2 + TN - 1) / TN)), dim3(256),
-                           (size_t)TN * (S + 1) * sizeof(cf), st, work, out + done * S, s2, stop, S, TN, plane);
+                           (size_t)TN * (S + 1) * sizeof(cf), st, work, out + done * opitch, s2, stop, S, TN, plane, opitch);
         HIPCHECK(hipGetLastError());
     }
     return PBH_OK;
@@ -565,6 +584,8 @@ struct IoLayout {
     int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
     int64_t in_pitch = 0, out_pitch = 0;
     int64_t in_valid = -1;   // sample-major input: time samples present (the rest of nsample is zero padding); -1 = all
+    int64_t out_row_elems = 0;   // sample-major output: elements between consecutive rows (0 = compact, S): the rows are a
+                                 // channel slice of a wider (nout, nchan_total, npol) array (pbh_dedisperse_slice)
 };
 
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
@@ -682,12 +703,42 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 }});
             }
         }
-        steps.push_back({"k_col_fwd", [=](hipStream_t st) {
-            return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
-        }});
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, p->perm_w,
                      reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
         rp.cP = chirp_split;
+        // rows outside [start, stop) are never read by k_reinterleave: skip their stores
+        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
+        ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
+#ifndef PBH_F64
+        // Depth-first schedule (PBH_DEPTH=1 per series, 2 per channel): the three middle passes run unit by unit, so a
+        // unit's planar intermediate (134 MB per series at N = 2^24) is still in the 256 MB Infinity Cache when the
+        // next pass reads it.
+        const int depth = depth_mode();
+        if (depth && P == 1 && colp && !in_sm && !out_sm && p->has_phase && row_phase_enabled() &&
+            3 * S + 3 <= kCounters) {
+            const int unit = depth == 1 ? 1 : p->npol;
+            const int npol = p->npol;
+            int ci = 3;
+            for (int s0 = 0; s0 < S; s0 += unit) {
+                ColpParams a = cp1;
+                a.data = work + (int64_t)s0 * N;
+                a.S = unit;
+                a.counter = ctr + ci++;
+                steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colq<OP_FWD_TW>(Q, a, st); }});
+                RowpParams r{work + (int64_t)s0 * N, p->chirp_phase + (int64_t)(s0 / npol) * N, p->tw16k, 1, N1, unit,
+                             (real)(1.0 / (double)p->N), ctr + ci++};
+                steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(r, st); }});
+                ColpParams b = cp3;
+                b.data = work + (int64_t)s0 * N;
+                b.S = unit;
+                b.counter = ctr + ci++;
+                steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colq<OP_TW_INV>(Q, b, st); }});
+            }
+        } else {
+#endif
+        steps.push_back({"k_col_fwd", [=](hipStream_t st) {
+            return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
+        }});
 #ifndef PBH_F64
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
@@ -696,9 +747,6 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         } else
 #endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
-        // rows outside [start, stop) are never read by k_reinterleave: skip their stores
-        ColParams c3{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, start, stop, 0};
-        ColpParams cp3{work, N, S, N2, tw, p->tw16k, start, stop, 0, ctr + 1};
         if (out_sm && !tail.out && P == 1) {   // pass 3 writes the caller's series-major output directly, cropped
             cp3.ld = work;
             cp3.ld_plane = N;
@@ -714,6 +762,9 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         steps.push_back({"k_col_inv", [=](hipStream_t st) {
             return colp ? launch_colq<OP_TW_INV>(Q, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
+#ifndef PBH_F64
+        }
+#endif
         const bool fuse_out = fuse_radix && !tail.out;   // the detect tail reads time-ordered planar data
         if (P > 1 && !fuse_out) {
             if (out_sm && !tail.out) {   // the inverse stage writes the caller's series-major output, cropped
@@ -742,8 +793,9 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 return launch_reint_radix(S, P, work, out, N, N2, N1, start, stop, st);
             }});
         } else if (!out_sm) {
+            const int64_t orow = io.out_row_elems;
             steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-                return launch_reinterleave(work, out, start, stop, S, N, st);
+                return launch_reinterleave(work, out, start, stop, S, N, st, orow);
             }});
         }
     } else {
@@ -771,7 +823,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         unsigned* ctr0 = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
         auto first = steps[0].launch;
         steps[0].launch = [=](hipStream_t st) {
-            HIPCHECK(hipMemsetAsync(ctr0, 0, 3 * sizeof(unsigned), st));
+            HIPCHECK(hipMemsetAsync(ctr0, 0, kCounterBytes, st));
             return first(st);
         };
     }
@@ -804,16 +856,24 @@ struct Bounce {
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
+thread_local Bounce g_bounce[16];
+void release_bounce_buffers() {   // pbh_trim: 16 MiB of pinned memory per (thread, device) that used a host transfer
+    for (Bounce& b : g_bounce)
+        for (int i = 0; i < 2; ++i) {
+            if (b.ev[i]) { hipEventSynchronize(b.ev[i]); hipEventDestroy(b.ev[i]); b.ev[i] = nullptr; }
+            if (b.buf[i]) { hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
+        }
+}
 Bounce* bounce_for_current_device() {
-    static thread_local Bounce table[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Bounce& b = table[dev];
+    Bounce& b = g_bounce[dev];
     if (!b.buf[0]) {
         for (int i = 0; i < 2; ++i) {
             if (hipHostMalloc(&b.buf[i], kBounceBytes, hipHostMallocDefault) != hipSuccess ||
                 hipEventCreateWithFlags(&b.ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
+                release_bounce_buffers();
                 return nullptr;
             }
         }
@@ -865,6 +925,20 @@ static hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hi
         }
     }
     return e;
+}
+
+// Page-lock a caller's host range for asynchronous copies.  0: registered here (unregister afterwards); 1: the caller
+// had pinned it already (both ends of the range are host-registered memory); -1: it cannot be pinned.
+static int pin_host_range(void* ptr, size_t bytes) {
+    if (bytes == 0) return 1;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    hipPointerAttribute_t a0, a1;
+    const bool ok = hipPointerGetAttributes(&a0, ptr) == hipSuccess && a0.type == hipMemoryTypeHost &&
+                    hipPointerGetAttributes(&a1, (char*)ptr + bytes - 1) == hipSuccess && a1.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return ok ? 1 : -1;
 }
 
 // Layout conversion of a device (nsample, nseries) array (DeviceArray.to_series_major / contiguous): one transposing
@@ -1331,7 +1405,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
             double a = -2.0 * M_PI * (double)i / (double)kTwTable;
             h[i] = make_cf((real)cos(a), (real)sin(a));
         }
-        if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable + 16)) != PBH_OK) return bail(rc);  // + k_colq's tile counters
+        if ((rc = dev_alloc(p, (void**)&p->tw16k, sizeof(cf) * kTwTable + kCounterBytes)) != PBH_OK) return bail(rc);  // + the persistent kernels' tile counters
         if (hipMemcpy(p->tw16k, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(PBH_ERR_HIP, "hipMemcpy(tw16k) failed"));
     }
@@ -1456,18 +1530,31 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     return PBH_OK;
 }
 
-int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) {
+int pbh_chirp_upload_as(pbh_plan* p, const void* chirp, int chirp_dtype, int loc);
+int pbh_chirp_upload(pbh_plan* p, const void* chirp_c64, int loc) { return pbh_chirp_upload_as(p, chirp_c64, PBH_C64, loc); }
+
+// chirp_dtype: PBH_C64 (what the reference's own chirps are, dedispersion.py:23) or, for complex128 plans, PBH_C128 -- the
+// reference multiplies by whatever array it is given (dedispersion.py:124-125), so a complex128 chirp keeps its precision
+int pbh_chirp_upload_as(pbh_plan* p, const void* chirp_c64, int chirp_dtype, int loc) {
     if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (chirp_dtype != PBH_C64 && chirp_dtype != PBH_C128) return fail(PBH_ERR_INVALID, "chirp dtype must be PBH_C64 or PBH_C128");
+    if (chirp_dtype == PBH_C128 && sizeof(cf) != sizeof(double2))
+        return fail(PBH_ERR_UNSUPPORTED, "a complex128 chirp needs a complex128 plan (the host promotes the data as numpy would)");
     HIPCHECK(hipSetDevice(p->device));
-    const size_t bytes = sizeof(float2) * (size_t)p->nchan * p->N;  // the external chirp is complex64
-    const float2* src = (const float2*)chirp_c64;
+    const size_t esz = chirp_dtype == PBH_C128 ? sizeof(double2) : sizeof(float2);
+    const size_t bytes = esz * (size_t)p->nchan * p->N;
+    const void* src = chirp_c64;
     if (loc == PBH_HOST) {
         PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, bytes));
         HIPCHECK(xfer_h2d(p->stage_in, chirp_c64, bytes, p->stream));
-        src = (const float2*)p->stage_in;
+        src = p->stage_in;
     }
-    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, src, (float2*)nullptr,
-                       (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
+    if (chirp_dtype == PBH_C128)
+        hipLaunchKernelGGL(k_chirp_reorder<double2>, dim3(2048), dim3(256), 0, p->stream, (const double2*)src, (double2*)nullptr,
+                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
+    else
+        hipLaunchKernelGGL(k_chirp_reorder<float2>, dim3(2048), dim3(256), 0, p->stream, (const float2*)src, (float2*)nullptr,
+                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
@@ -1486,7 +1573,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
         PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, bytes));
         dst = (float2*)p->stage_out;
     }
-    hipLaunchKernelGGL(k_chirp_reorder, dim3(2048), dim3(256), 0, p->stream, (const float2*)nullptr, dst,
+    hipLaunchKernelGGL(k_chirp_reorder<float2>, dim3(2048), dim3(256), 0, p->stream, (const float2*)nullptr, dst,
                        (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w, p->P);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
@@ -1616,22 +1703,10 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
     if (nout == 0) return PBH_OK;
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
-    // per-thread device copy of the delays, grown on demand (copies and kernels are ordered on the stream)
-    static thread_local int64_t* d = nullptr;
-    static thread_local int d_cap = 0, d_dev = -1;
-    static thread_local hipStream_t d_stream = nullptr;
-    if (d && d_stream != st) HIPCHECK(hipDeviceSynchronize());   // the previous user (another stream, possibly gone by now) may still be reading
-    if (!d || d_cap < nchan || d_dev != device) {
-        if (d) {
-            HIPCHECK(hipDeviceSynchronize());
-            hipFree(d);
-            d = nullptr;
-        }
-        PBHCHECK(dev_alloc(nullptr, (void**)&d, sizeof(int64_t) * (size_t)nchan));
-        d_cap = nchan;
-        d_dev = device;
-    }
-    d_stream = st;
+    // device copy of the delays: allocated and freed in stream order (no device-wide synchronisation, nothing cached
+    // per thread); the host array is staged by the copy before it returns
+    int64_t* d = nullptr;
+    HIPCHECK(hipMallocAsync((void**)&d, sizeof(int64_t) * (size_t)nchan, st));
     hipError_t e = xfer_h2d(d, delay, sizeof(int64_t) * (size_t)nchan, st);
     if (e == hipSuccess) {
         constexpr int U = 8;
@@ -1647,6 +1722,8 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
                                (uint32_t*)out_dev, (const int64_t*)d, nout, nchan, unit);
         e = hipGetLastError();
     }
+    const hipError_t ef = hipFreeAsync(d, st);
+    if (e == hipSuccess) e = ef;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_incoherent: ") + hipGetErrorString(e));
     return PBH_OK;
 }
@@ -1751,6 +1828,67 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     return PBH_OK;
 }
 
+static int launch_place(hipStream_t st, const cf* src, int64_t ipitch, cf* dst, int64_t opitch, int64_t nrow, int ncol) {
+    // 16-byte vectors when every row of both sides starts and ends on one
+    const bool v16 = sizeof(cf) == 16 || (ncol % 2 == 0 && ipitch % 2 == 0 && opitch % 2 == 0 &&
+                                          (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    const int64_t units = v16 && sizeof(cf) == 8 ? nrow * (ncol / 2) : nrow * ncol;
+    int64_t blocks = (units + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (v16 && sizeof(cf) == 8)
+        hipLaunchKernelGGL((k_place<float4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)src, ipitch / 2, (float4*)dst,
+                           opitch / 2, nrow, ncol / 2);
+    else
+        hipLaunchKernelGGL((k_place<cf>), dim3((unsigned)blocks), dim3(256), 0, st, src, ipitch, dst, opitch, nrow, ncol);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+
+// true when the plan's last kernel can write pitched rows itself (launch_reinterleave's row transposes / generic kernel)
+static bool slice_fast_ok(const pbh_plan* p) {
+    if (p->bsL || p->N1 == 1 || resolved_variant(p) != PBH_VARIANT_PLANAR5) return false;
+    if (p->P > 1 && radix_layout_ok(p->S, p->P, p->N, p->N2)) return false;   // the inverse radix stage rides in the layout pass
+    return blk_series(p->S, p->N) == 0;
+}
+
+// The multi-GPU gather: a rank's (nout, nchan_local, npol) result is written straight into its
+// channel slice of the full-band (nout, nchan_total, npol) block -- which may live on a peer GPU (pbh_node_import) --
+// by the pipeline's last kernel, instead of transpose + all-gather + concatenate + transpose afterwards.
+int pbh_dedisperse_slice(pbh_plan* p, const void* in_dev, void* out_dev, int64_t out_row_elems, int64_t out_col_offset) {
+    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    if (out_col_offset < 0 || out_row_elems < out_col_offset + p->S)
+        return fail(PBH_ERR_INVALID, "pbh_dedisperse_slice: the slice [offset, offset + nchan*npol) does not fit the output row");
+    HIPCHECK(hipSetDevice(p->device));
+    const int64_t nout = p->stop - p->start;
+    if (nout <= 0) return PBH_OK;
+    cf* base = (cf*)out_dev + out_col_offset;
+    if (out_row_elems == p->S || slice_fast_ok(p)) {
+        IoLayout io;
+        io.out_row_elems = out_row_elems == p->S ? 0 : out_row_elems;
+        auto steps = build_steps(p, (const cf*)in_dev, base, DetectTail(), io);
+        return run_steps(steps, p->stream);
+    }
+    // other pipelines (single tile, 3-pass, two-axis layout tiles, arbitrary lengths): compact result, then one placing pass
+    const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)nout;
+    PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, bytes));
+    auto steps = build_steps(p, (const cf*)in_dev, (cf*)p->stage_out);
+    PBHCHECK(run_steps(steps, p->stream));
+    return launch_place(p->stream, (const cf*)p->stage_out, p->S, base, out_row_elems, nout, p->S);
+}
+
+// 2-D copy between sample-major device arrays of this build's complex dtype: nrow rows of ncol elements, row pitches
+// in elements.  dst may be a peer GPU's buffer (pbh_node_import): this is the push of the all-gather.
+int pbh_place(int device, void* hip_stream, int /*dtype: this build's*/, const void* src_dev, int64_t src_row_elems,
+              void* dst_dev, int64_t dst_row_elems, int64_t nrow, int64_t ncol) {
+    if (!src_dev || !dst_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nrow < 0 || ncol < 0 || ncol > 0x7fffffff || src_row_elems < ncol || dst_row_elems < ncol)
+        return fail(PBH_ERR_INVALID, "pbh_place: bad geometry");
+    if (nrow == 0 || ncol == 0) return PBH_OK;
+    HIPCHECK(hipSetDevice(device));
+    return launch_place((hipStream_t)hip_stream, (const cf*)src_dev, src_row_elems, (cf*)dst_dev, dst_row_elems, nrow, (int)ncol);
+}
+
 static int detect_out_elems(int mode, int npol) {
     switch (mode) {
         case PBH_DETECT_INTENSITY: return npol;
@@ -1789,7 +1927,10 @@ int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const 
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &sin, in_bytes)) != PBH_OK) return rc;
-        xfer_h2d(sin, in_c64, in_bytes, st);
+        if (xfer_h2d(sin, in_c64, in_bytes, st) != hipSuccess) {
+            hipFree(sin);
+            return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
+        }
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
@@ -1895,6 +2036,27 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
 // Per-thread caches of the plans behind the plan-less entry points (pbh_fft_c2c, pbh_stft): two Bluestein ring
 // plans and two native transform plans, each owning a workspace the size of its data.  pbh_trim() frees them.
 struct CachedPlan { int device; int64_t n, batch; pbh_plan* plan; };
+// stage twiddle table W_16384^p of the stand-alone one-tile transforms: one per (thread, device), freed by pbh_trim
+static thread_local cf* g_tw_table[16] = {};
+static int standalone_twiddles(int device, cf** out) {
+    if (device < 0 || device >= 16) return fail(PBH_ERR_INVALID, "device index out of range");
+    if (!g_tw_table[device]) {
+        std::vector<cf> h(kTwTable);
+        for (int i = 0; i < kTwTable; ++i) {
+            double a = -2.0 * M_PI * (double)i / (double)kTwTable;
+            h[i] = make_cf((real)cos(a), (real)sin(a));
+        }
+        cf* t = nullptr;
+        PBHCHECK(dev_alloc(nullptr, (void**)&t, sizeof(cf) * kTwTable));
+        if (hipMemcpy(t, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(t);
+            return fail(PBH_ERR_HIP, "hipMemcpy(twiddles) failed");
+        }
+        g_tw_table[device] = t;
+    }
+    *out = g_tw_table[device];
+    return PBH_OK;
+}
 static thread_local CachedPlan g_ring_cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
 static thread_local CachedPlan g_native_cache[2] = {{-1, 0, 0, nullptr}, {-1, 0, 0, nullptr}};
 
@@ -1905,6 +2067,18 @@ int pbh_trim(void) {
                 pbh_plan_destroy(cache[i].plan);
                 cache[i] = CachedPlan{-1, 0, 0, nullptr};
             }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < 16; ++d)
+        if (g_tw_table[d]) {   // freed on the device that owns it, after its work has drained
+            if (hipSetDevice(d) == hipSuccess) {
+                hipDeviceSynchronize();
+                hipFree(g_tw_table[d]);
+            }
+            g_tw_table[d] = nullptr;
+        }
+    if (have_cur) hipSetDevice(cur);
+    release_bounce_buffers();
     return PBH_OK;
 }
 
@@ -2077,18 +2251,8 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     const bool one_tile = is_pow2(n) && n >= PBH_R && n <= kTilePoints;
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
-    static thread_local cf* tw = nullptr;
-    static thread_local int tw_dev = -1;
-    if (one_tile && (!tw || tw_dev != device)) {
-        std::vector<cf> h(kTwTable);
-        for (int i = 0; i < kTwTable; ++i) {
-            double a = -2.0 * M_PI * (double)i / (double)kTwTable;
-            h[i] = make_cf((real)cos(a), (real)sin(a));
-        }
-        PBHCHECK(dev_alloc(nullptr, (void**)&tw, sizeof(cf) * kTwTable));
-        HIPCHECK(hipMemcpy(tw, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice));
-        tw_dev = device;
-    }
+    cf* tw = nullptr;
+    if (one_tile) PBHCHECK(standalone_twiddles(device, &tw));
     const size_t bytes = sizeof(cf) * (size_t)n * batch;
     const cf* din = (const cf*)in_c64;
     cf* dout = (cf*)out_c64;
@@ -2096,7 +2260,10 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &sin, bytes));
-        xfer_h2d(sin, in_c64, bytes, st);
+        if (xfer_h2d(sin, in_c64, bytes, st) != hipSuccess) {
+            hipFree(sin);
+            return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
+        }
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
@@ -2145,7 +2312,10 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
     int rc = PBH_OK;
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &stg_in, bytes));
-        xfer_h2d(stg_in, in, bytes, st);
+        if (xfer_h2d(stg_in, in, bytes, st) != hipSuccess) {
+            hipFree(stg_in);
+            return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
+        }
         din = (const cf*)stg_in;
     }
     if (out_loc == PBH_HOST) {
@@ -2160,19 +2330,8 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
         hipError_t e1 = hipMemcpyAsync(dout, din, bytes, hipMemcpyDeviceToDevice, st);
         if (e1 != hipSuccess) rc = fail(PBH_ERR_HIP, "hipMemcpyAsync failed");
     } else if (is_pow2(n) && n >= PBH_R && n <= kTilePoints) {
-        static thread_local cf* tw = nullptr;
-        static thread_local int tw_dev = -1;
-        if (!tw || tw_dev != device) {
-            std::vector<cf> h(kTwTable);
-            for (int i = 0; i < kTwTable; ++i) {
-                double a = -2.0 * M_PI * (double)i / (double)kTwTable;
-                h[i] = make_cf((real)cos(a), (real)sin(a));
-            }
-            rc = dev_alloc(nullptr, (void**)&tw, sizeof(cf) * kTwTable);
-            if (rc == PBH_OK && hipMemcpy(tw, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess)
-                rc = fail(PBH_ERR_HIP, "hipMemcpy(twiddles) failed");
-            tw_dev = device;
-        }
+        cf* tw = nullptr;
+        rc = standalone_twiddles(device, &tw);
         if (rc == PBH_OK && n == kTilePoints && inner % 2 == 0 && stft_pair_enabled()) {
             // one segment of one series fills a tile: a workgroup takes both series of a pair (k_seg_pair)
             auto kern = k_seg_pair<kTilePoints, PBH_R>;
@@ -2394,9 +2553,13 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
         if (rc == PBH_OK) hipok(xfer_h2d(dconj, conj_mask, (size_t)p->S, p->stream), "mask copy");
     }
     if (rc == PBH_OK) {
-        reg_in = hipHostRegister(const_cast<void*>(host_raw), raw_bytes, hipHostRegisterDefault) == hipSuccess;
-        reg_out = hipHostRegister(host_out, host_out_bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
+        const int pi = pin_host_range(const_cast<void*>(host_raw), raw_bytes);   // see pbh_dedisperse_stream
+        const int po = pin_host_range(host_out, host_out_bytes);
+        reg_in = pi == 0;
+        reg_out = po == 0;
+        if (pi < 0 || po < 0)
+            rc = fail(PBH_ERR_HIP, "pbh_dedisperse_stream_raw: the host buffers cannot be page-locked (hipHostRegister failed); "
+                                   "pageable memory is never handed to asynchronous copies");
         hipok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
         hipok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
         hipok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
@@ -2480,7 +2643,16 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
     HIPCHECK(hipSetDevice(p->device));
     auto steps = build_steps(p, (const cf*)in_dev, (cf*)out_dev);
     const int nk = (int)steps.size();
-    if (nk > PBH_MAX_KERNELS) return fail(PBH_ERR_INVALID, "too many kernels");
+    // steps that share a name (the depth-first schedule launches each middle pass once per series) report as one entry
+    std::vector<const char*> uniq;
+    std::vector<int> slot(nk);
+    for (int k = 0; k < nk; ++k) {
+        int j = 0;
+        while (j < (int)uniq.size() && strcmp(uniq[j], steps[k].name) != 0) ++j;
+        if (j == (int)uniq.size()) uniq.push_back(steps[k].name);
+        slot[k] = j;
+    }
+    if ((int)uniq.size() > PBH_MAX_KERNELS) return fail(PBH_ERR_INVALID, "too many kernels");
     std::vector<hipEvent_t> ev(nk + 1);
     for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
     std::vector<double> acc(nk, 0.0);
@@ -2500,11 +2672,12 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
     }
     for (auto& e : ev) hipEventDestroy(e);
     PBHCHECK(rc);
-    for (int k = 0; k < nk; ++k) {
-        ms_per_kernel[k] = (float)(acc[k] / iters);
-        if (names) names[k] = steps[k].name;
+    for (int j = 0; j < (int)uniq.size(); ++j) {
+        ms_per_kernel[j] = 0.f;
+        if (names) names[j] = uniq[j];
     }
-    *nkernel = nk;
+    for (int k = 0; k < nk; ++k) ms_per_kernel[slot[k]] += (float)(acc[k] / iters);
+    *nkernel = (int)uniq.size();
     return PBH_OK;
 }
 

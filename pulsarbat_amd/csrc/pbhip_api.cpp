@@ -3,6 +3,9 @@
 // the pbh_* symbols and forwards on the plan's dtype.
 #include "../../include/pbhip.h"
 
+#include <hip/hip_runtime.h>
+
+#include <cstring>
 #include <string>
 
 #define PBH_DECLARE_IMPL(P)                                                                                     \
@@ -16,6 +19,7 @@
     int P##plan_info(const P##plan*, pbh_plan_info_t*);                                                         \
     int P##chirp_generate(P##plan*, double, double, const double*, double);                                     \
     int P##chirp_upload(P##plan*, const void*, int);                                                            \
+    int P##chirp_upload_as(P##plan*, const void*, int, int);                                                    \
     int P##chirp_download(P##plan*, void*, int);                                                                \
     int P##chirp_special(P##plan*, const double*, int);                                                         \
     int P##mix(int, void*, int, const void*, void*, int64_t, int, const double*);                               \
@@ -25,10 +29,12 @@
     int P##transfer(int, void*, void*, const void*, size_t, int);                                               \
     int P##trim(void);                                                                                          \
     int P##relayout(int, void*, int, const void*, int, int64_t, void*, int, int64_t, int64_t, int);            \
+    int P##place(int, void*, int, const void*, int64_t, void*, int64_t, int64_t, int64_t);                     \
     int P##decode(int, void*, const void*, size_t, int, const pbh_raw_layout_t*, int64_t, int64_t, int, int,    \
                   const unsigned char*, float, void*, int, int64_t);                                            \
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
+    int P##dedisperse_slice(P##plan*, const void*, void*, int64_t, int64_t);                                    \
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
@@ -115,6 +121,9 @@ int pbh_chirp_generate(pbh_plan* p, double c, double dt, const double* f, double
     FORWARD(p, pbh32_chirp_generate(P32(p), c, dt, f, r), pbh64_chirp_generate(P64(p), c, dt, f, r));
 }
 int pbh_chirp_upload(pbh_plan* p, const void* c, int loc) { FORWARD(p, pbh32_chirp_upload(P32(p), c, loc), pbh64_chirp_upload(P64(p), c, loc)); }
+int pbh_chirp_upload_as(pbh_plan* p, const void* c, int dt, int loc) {
+    FORWARD(p, pbh32_chirp_upload_as(P32(p), c, dt, loc), pbh64_chirp_upload_as(P64(p), c, dt, loc));
+}
 int pbh_chirp_download(pbh_plan* p, void* c, int loc) { FORWARD(p, pbh32_chirp_download(P32(p), c, loc), pbh64_chirp_download(P64(p), c, loc)); }
 int pbh_chirp_special(pbh_plan* p, const double* a, int m) { FORWARD(p, pbh32_chirp_special(P32(p), a, m), pbh64_chirp_special(P64(p), a, m)); }
 int pbh_mix(int device, void* stream, int dtype, const void* in, void* out, int64_t n, int ns, const double* ft) {
@@ -158,6 +167,11 @@ int pbh_relayout(int device, void* stream, int dtype, const void* in, int il, in
     if (dtype == PBH_C64) return done(PBH_C64, pbh32_relayout(device, stream, dtype, in, il, ip, out, ol, op, n, nseries));
     return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
 }
+int pbh_place(int device, void* stream, int dtype, const void* src, int64_t sp, void* dst, int64_t dp, int64_t nrow, int64_t ncol) {
+    if (dtype == PBH_C128) return done(PBH_C128, pbh64_place(device, stream, dtype, src, sp, dst, dp, nrow, ncol));
+    if (dtype == PBH_C64) return done(PBH_C64, pbh32_place(device, stream, dtype, src, sp, dst, dp, nrow, ncol));
+    return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
 int pbh_trim(void) {
     pbh32_trim();
     pbh64_trim();
@@ -168,6 +182,9 @@ int pbh_transfer(int device, void* stream, void* dst, const void* src, size_t by
 }
 int pbh_dedisperse_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ol, int64_t op) {
     FORWARD(p, pbh32_dedisperse_layout(P32(p), in, il, ip, out, ol, op), pbh64_dedisperse_layout(P64(p), in, il, ip, out, ol, op));
+}
+int pbh_dedisperse_slice(pbh_plan* p, const void* in, void* out, int64_t row, int64_t off) {
+    FORWARD(p, pbh32_dedisperse_slice(P32(p), in, out, row, off), pbh64_dedisperse_slice(P64(p), in, out, row, off));
 }
 int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ns, int mode) {
     FORWARD(p, pbh32_dedisperse_detect_layout(P32(p), in, il, ip, out, ns, mode), pbh64_dedisperse_detect_layout(P64(p), in, il, ip, out, ns, mode));
@@ -205,5 +222,67 @@ int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* m
     FORWARD(p, pbh32_plan_profile(P32(p), in, out, iters, ms, nk, names), pbh64_plan_profile(P64(p), in, out, iters, ms, nk, names));
 }
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms) { return done(PBH_C64, pbh32_copy_bench(device, bytes, iters, ms)); }
+
+// ---- node-level sharing of device buffers between the ranks of one node (one process per GPU) -----------------
+// The reference gathers chunked results with Signal.compute() (pulsarbat/core.py:298-309).  Here the gather is done by
+// the producers: the destination rank allocates the full-band block (pbh_node_alloc), exports it (pbh_node_export), the
+// other ranks map it (pbh_node_import, xGMI peer access) and their pipelines write their channel slices into it
+// (pbh_dedisperse_slice).  Handle exchange and the closing barrier are the host's business (torch.distributed).
+static_assert(sizeof(hipIpcMemHandle_t) == sizeof(pbh_ipc_handle_t), "pbh_ipc_handle_t must hold a hipIpcMemHandle_t");
+
+static int hip_fail(const char* what, hipError_t e) {
+    g_last = -1;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return PBH_ERR_HIP;
+}
+
+int pbh_node_alloc(int device, size_t bytes, void** dev_ptr) {
+    if (!dev_ptr || bytes == 0) return fail_here(PBH_ERR_INVALID, "pbh_node_alloc: bad argument");
+    *dev_ptr = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    e = hipMalloc(dev_ptr, bytes);   // a whole allocation of its own: exportable, unlike a caching allocator's sub-block
+    if (e != hipSuccess) {
+        g_last = -1;
+        g_err = std::string("pbh_node_alloc: hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        return PBH_ERR_NOMEM;
+    }
+    return PBH_OK;
+}
+
+int pbh_node_free(int device, void* dev_ptr) {
+    if (!dev_ptr) return PBH_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // peers may only just have finished writing
+    if (e == hipSuccess) e = hipFree(dev_ptr);
+    return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_free", e);
+}
+
+int pbh_node_export(int device, void* dev_ptr, pbh_ipc_handle_t* handle) {
+    if (!dev_ptr || !handle) return fail_here(PBH_ERR_INVALID, "pbh_node_export: NULL argument");
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle), dev_ptr);
+    return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_export: hipIpcGetMemHandle", e);
+}
+
+int pbh_node_import(int device, const pbh_ipc_handle_t* handle, void** dev_ptr) {
+    if (!dev_ptr || !handle) return fail_here(PBH_ERR_INVALID, "pbh_node_import: NULL argument");
+    *dev_ptr = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, handle, sizeof(h));
+        e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+    }
+    return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_import: hipIpcOpenMemHandle", e);
+}
+
+int pbh_node_release(int device, void* dev_ptr) {
+    if (!dev_ptr) return PBH_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcCloseMemHandle(dev_ptr);
+    return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_release: hipIpcCloseMemHandle", e);
+}
 
 }  // extern "C"

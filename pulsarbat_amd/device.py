@@ -106,13 +106,14 @@ class DeviceArray:
             return a
         a = np.ascontiguousarray(a)
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
-        if np.dtype(a.dtype) not in _maps() or a.size == 0:
-            return cls(torch.from_numpy(a).to(dev))
-        # through the library's pinned bounce buffers, not torch's copy: pageable numpy memory handed to
-        # the HIP runtime gets pinned on the fly and the pin is cached beyond the array's life
-        from . import _hip
-        t = torch.empty(a.shape, dtype=_maps()[np.dtype(a.dtype)], device=dev)
-        _hip.transfer(dev.index, t.data_ptr(), a.ctypes.data, a.nbytes, to_host=False)
+        # every dtype goes through the library's pinned bounce buffers (pbh_transfer), not torch's copy: pageable numpy
+        # memory handed to the HIP runtime gets pinned on the fly and the pin is cached beyond the array's life
+        # (DESIGN.md 6).  The torch dtype is whatever torch maps the numpy dtype to (TypeError if it has none).
+        tdt = _maps().get(np.dtype(a.dtype)) or torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
+        t = torch.empty(a.shape, dtype=tdt, device=dev)
+        if a.size:
+            from . import _hip
+            _hip.transfer(dev.index, t.data_ptr(), a.ctypes.data, a.nbytes, to_host=False)
         return cls(t)
 
     # --- array protocol used by Signal ---------------------------------------------------
@@ -138,6 +139,14 @@ class DeviceArray:
             if td == self._t.dtype:
                 return npd
         raise TypeError(f"unsupported tensor dtype {self._t.dtype}")
+
+    def _np_dtype(self):
+        """numpy dtype of the tensor, including the ones the Signal protocol does not use (integer payloads, masks)."""
+        try:
+            return self.dtype
+        except TypeError:
+            import torch
+            return torch.empty(0, dtype=self._t.dtype).numpy().dtype
 
     @property
     def size(self):
@@ -179,9 +188,9 @@ class DeviceArray:
         """Host copy as numpy."""
         t = self.contiguous()._t
         if t.numel() == 0:
-            return t.cpu().numpy()
+            return np.empty(tuple(t.shape), dtype=self._np_dtype())
         from . import _hip
-        out = np.empty(tuple(t.shape), dtype=self.dtype)
+        out = np.empty(tuple(t.shape), dtype=self._np_dtype())
         _hip.transfer(t.device.index, out.ctypes.data, t.data_ptr(), out.nbytes, to_host=True)
         return out
 

@@ -12,6 +12,7 @@ import numpy as np
 
 from .. import units as u
 from .. import _hip
+from ..device import DeviceArray
 from ..core import Signal, BasebandSignal, IntensitySignal, DualPolarizationSignal, FullStokesSignal
 from ..utils import real_to_complex
 from ._base import BaseReader
@@ -146,7 +147,7 @@ def _conj_where(t, mask):
     """Conjugate the series of device tensor ``t`` selected by the boolean ``mask`` (real-sampled data only: their
     complex form exists only after real_to_complex, so the decode pass cannot do it)."""
     import torch
-    m = torch.as_tensor(np.broadcast_to(mask, t.shape[1:]).copy(), device=t.device)
+    m = DeviceArray.from_host(np.broadcast_to(mask, t.shape[1:]).copy(), device=t.device.index).tensor
     return torch.where(m, t.conj(), t).resolve_conj()
 
 

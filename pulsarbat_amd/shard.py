@@ -6,9 +6,15 @@ the edges of the FULL band (dedispersion.py:127-131).  That is the decomposition
 gets from Dask chunks over the non-time axes (core.py:332-345); here a chunk is a rank's
 contiguous block of channels (both polarisations stay together so the chirp is shared and
 Stokes detection stays local).  There is no data-path collective: ranks generate their own
-chirps from scalars.  ``gather=True`` adds the one real exchange step, an all-gather of the
-output along the channel axis (RCCL over xGMI for device data, gloo for host data) -- the
-analogue of ``Signal.compute()`` on a chunked dask array.
+chirps from scalars.  Two optional exchange steps exist:
+
+* ``chirp=`` with ``chirp_src=r``: rank ``r`` holds a user-supplied full-band chirp and the ranks
+  receive their channel blocks of it (one scatter over RCCL / gloo; a chirp shared by all channels is
+  one broadcast) -- the sharded form of dedispersion.py:121-124.
+* ``gather=``: the analogue of ``Signal.compute()`` on a chunked dask array (core.py:298-309).  For
+  device data the ranks' pipelines write their channel slices directly into the destination ranks'
+  full-band blocks over xGMI (``pulsarbat_amd.node.ChannelGather``: ``pbh_node_*`` +
+  ``pbh_dedisperse_slice``); host data is gathered with a gloo all-gather.
 """
 
 import math
@@ -18,7 +24,7 @@ import numpy as np
 from . import units as u
 from .core import BasebandSignal
 
-__all__ = ["channel_slice", "shard_signal", "coherent_dedispersion_sharded"]
+__all__ = ["channel_slice", "shard_signal", "coherent_dedispersion_sharded", "dedisperse_detect_sharded"]
 
 
 def channel_slice(nchan, world, rank):
@@ -46,48 +52,193 @@ def _full_band_crop(dm, nsample, sample_rate, band_min, band_max, ref_freq):
     return math.ceil(-min(0, top, bot)), nsample - math.ceil(max(0, top, bot))
 
 
-def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, group=None,
-                                  gather=False, variant="auto", _transform=None):
+def _rank_device(z_local, device):
+    """The GPU this rank computes on: the data's own device, else ``device=``, else the process's current
+    device (one process per GPU: ``torch.cuda.set_device(LOCAL_RANK)``) -- never a fixed GPU 0."""
+    from .device import DeviceArray
+    if isinstance(z_local.data, DeviceArray):
+        return z_local.data.device_index
+    if device is not None:
+        return int(device)
+    import torch
+    return torch.cuda.current_device()
+
+
+def _scatter_chirp(chirp, src, counts, rank, group, device):
+    """Rank ``src`` holds a full-band chirp (channels on axis 1); every rank gets its channel block.
+    A chirp with a single channel row (shared by all channels) is broadcast whole.  The payload travels as a
+    real view over RCCL (device tensors) or gloo (host tensors); shapes go first as a small object."""
+    import torch
+    import torch.distributed as dist
+    from .device import DeviceArray
+    backend = dist.get_backend(group)
+    on_gpu = backend == "nccl"
+    meta = [None]
+    if rank == src:
+        if on_gpu and not isinstance(chirp, DeviceArray):
+            chirp = DeviceArray.from_host(np.asarray(chirp), device=device)   # through pbh_transfer, not a torch copy
+        if not on_gpu and isinstance(chirp, DeviceArray):
+            chirp = chirp.get()
+        c = chirp.tensor if isinstance(chirp, DeviceArray) else torch.from_numpy(np.ascontiguousarray(chirp))
+        if c.dim() < 2:
+            c = c.reshape(tuple(c.shape) + (1,) * (2 - c.dim()))
+        meta = [(tuple(c.shape), str(c.dtype).replace("torch.", ""))]
+    dist.broadcast_object_list(meta, src=_global_rank(group, src), group=group)
+    shape, dname = meta[0]
+    tdtype = getattr(torch, dname)
+    dev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
+    world = len(counts)
+    if shape[1] == 1:   # one row for every channel: a plain broadcast of the chirp
+        buf = c.contiguous() if rank == src else torch.empty(shape, dtype=tdtype, device=dev)
+        view = torch.view_as_real(buf) if buf.is_complex() else buf
+        dist.broadcast(view, src=_global_rank(group, src), group=group)
+        mine = buf
+    else:
+        if shape[1] != sum(counts):
+            raise ValueError(f"the full-band chirp has {shape[1]} channels, the ranks hold {sum(counts)}")
+        cmax = max(counts)
+        pshape = (shape[0], cmax) + tuple(shape[2:])
+        recv = torch.empty(pshape, dtype=tdtype, device=dev)
+        pieces = None
+        if rank == src:
+            pieces, lo = [], 0
+            for n in counts:
+                piece = torch.zeros(pshape, dtype=tdtype, device=dev)
+                piece[:, :n] = c[:, lo:lo + n]
+                pieces.append(torch.view_as_real(piece) if piece.is_complex() else piece)
+                lo += n
+        dist.scatter(torch.view_as_real(recv) if recv.is_complex() else recv, pieces, src=_global_rank(group, src),
+                     group=group)
+        mine = recv[:, :counts[rank]].contiguous()
+    return DeviceArray(mine) if mine.is_cuda else mine.numpy()
+
+
+def _global_rank(group, r):
+    import torch.distributed as dist
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, chirp=None, chirp_src=None,
+                                  group=None, gather=False, root=0, device=None, variant="auto", _transform=None):
     """Dedisperse this rank's channel shard consistently with the full-band call.
 
     z_local   this rank's BasebandSignal shard (``shard_signal``), host or device resident
     band_min / band_max   ``min_freq`` / ``max_freq`` of the FULL signal (crop, dedispersion.py:127-128)
     ref_freq  reference frequency of the full call (the full signal's ``center_freq`` by default there)
-    gather    all-gather the shards along the channel axis and return the full-band signal on every
-              rank; otherwise the shard result stays where it is (``persist()`` semantics)
+    chirp     user-supplied chirp (dedispersion.py:121-124), unchecked as in the reference: this rank's block
+              (anything that broadcasts against ``z_local.data``), or -- with ``chirp_src=r`` -- the FULL-band
+              chirp on rank ``r`` only (``None`` elsewhere), scattered by channel
+    gather    ``False``: the shard result stays where it is (``persist()`` semantics);
+              ``True`` / ``"all"``: every rank gets the full-band signal; ``"root"``: only rank ``root`` does
+              (the others return ``None``: their slice was written into the root's block)
+    device    GPU for host-resident shards (default: the process's current device)
     _transform  test hook: ``f(x, start, stop, chan_freqs_hz, ref_hz) -> y`` replacing the HIP plan
                 (used by the CPU gloo tests with the oracle; never set by product code)
     """
     if not isinstance(z_local, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
+    if gather not in (False, True, "all", "root"):
+        raise ValueError("gather must be False, True / 'all' or 'root'")
     start, stop = _full_band_crop(DM, len(z_local), z_local.sample_rate, band_min, band_max, ref_freq)
     freqs = np.asarray(u.to_value(z_local.channel_freqs, u.Hz), dtype=np.float64)
     ref_hz = u.to_value(ref_freq, u.Hz)
-
-    if _transform is not None:
-        y = _transform(np.asarray(z_local.data), start, stop, freqs, ref_hz)
-    else:
-        from . import _hip
-        from .device import DeviceArray
-        from .transforms.dedispersion import _geometry
-        nsample, nchan, npol = _geometry(z_local)
-        on_device = isinstance(z_local.data, DeviceArray)
-        dev = z_local.data.device_index if on_device else 0
-        with _hip.Plan(nsample, nchan, npol, start, stop, device=dev, variant=variant, dtype=z_local.dtype) as plan:
-            plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, ref_hz)
-            x = z_local.data.contiguous() if on_device else np.ascontiguousarray(z_local.data)
-            y = plan.dedisperse(x)
-            if on_device:
-                import torch
-                torch.cuda.synchronize(dev)
-
     kw = {}
     if z_local.start_time is not None:
         kw["start_time"] = z_local.start_time + start / z_local.sample_rate
+
+    if _transform is not None:
+        y = _transform(np.asarray(z_local.data), start, stop, freqs, ref_hz)
+        out = type(z_local).like(z_local, y, **kw)
+        return out if not gather else _all_gather_channels(out, band_min, band_max, group)
+
+    from . import _hip
+    from .device import DeviceArray
+    from .transforms.dedispersion import _broadcast_chirp, _geometry
+    nsample, nchan, npol = _geometry(z_local)
+    on_device = isinstance(z_local.data, DeviceArray)
+    dev = _rank_device(z_local, device)
+    if chirp_src is not None:
+        import torch.distributed as dist
+        counts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(counts, int(nchan), group=group)
+        chirp = _scatter_chirp(chirp, int(chirp_src), [int(c) for c in counts], dist.get_rank(group), group, dev)
+    rows, per_pol, dtype = (None, False, np.dtype(z_local.dtype)) if chirp is None else _broadcast_chirp(chirp, z_local)
+    pchan, ppol = (nchan * npol, 1) if per_pol else (nchan, npol)
+    data = z_local.data if dtype == np.dtype(z_local.dtype) else z_local.data.astype(dtype)
+    x = data.contiguous() if on_device else np.ascontiguousarray(data)
+    center = (band_min + band_max) / 2
+    with _hip.Plan(nsample, pchan, ppol, start, stop, device=dev, variant=variant, dtype=dtype) as plan:
+        if rows is None:
+            plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, ref_hz)
+        else:
+            plan.chirp_upload(rows)
+        if gather and on_device:
+            from .node import ChannelGather
+            mode = "root" if gather == "root" else "all"
+            g = ChannelGather(plan.nout, pchan, ppol, dtype, dev, group=group, mode=mode, root=root)
+            try:
+                full = g.run(plan, x)
+            finally:
+                g.close()
+            if full is None:   # a non-root rank of a root gather: its slice went to the root, nothing stays here
+                return None
+            n_total = g.nchan_total // (npol if per_pol else 1)
+            full = DeviceArray(full.tensor.reshape((plan.nout, n_total) + tuple(z_local.shape[2:])))
+            return type(z_local).like(z_local, full, center_freq=center, freq_align="center", **kw)
+        else:
+            y = plan.dedisperse(x)
+        if on_device:
+            import torch
+            torch.cuda.synchronize(dev)
     out = type(z_local).like(z_local, y, **kw)
-    if not gather:
+    if not gather or on_device:
         return out
     return _all_gather_channels(out, band_min, band_max, group)
+
+
+def dedisperse_detect_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, mode="I", nscrunch=1, group=None,
+                              gather=False, device=None, variant="auto"):
+    """``dedisperse_detect`` (dedispersion + detection + ``nscrunch``-fold time sum, BASELINE configs[4]) on this
+    rank's channel shard with the FULL band's crop.  Returns ``(array, start)``: float32 ``(nout // nscrunch,
+    nchan_local[, npol | 4])``, or with ``gather=True`` the full-band ``(..., nchan_total, ...)`` array on every
+    rank -- the detected output is ~1/nscrunch of the voltages (2.2 MB at configs[4]), so this gather is one
+    small all-gather over RCCL (device data) or gloo (host data)."""
+    if not isinstance(z_local, BasebandSignal):
+        raise TypeError("Signal must be a BasebandSignal object.")
+    from . import _hip
+    from .device import DeviceArray
+    from .transforms.dedispersion import _geometry
+    start, stop = _full_band_crop(DM, len(z_local), z_local.sample_rate, band_min, band_max, ref_freq)
+    freqs = np.asarray(u.to_value(z_local.channel_freqs, u.Hz), dtype=np.float64)
+    nsample, nchan, npol = _geometry(z_local)
+    on_device = isinstance(z_local.data, DeviceArray)
+    dev = _rank_device(z_local, device)
+    x = z_local.data.contiguous() if on_device else np.ascontiguousarray(z_local.data)
+    with _hip.Plan(nsample, nchan, npol, start, stop, device=dev, variant=variant, dtype=z_local.dtype) as plan:
+        plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, u.to_value(ref_freq, u.Hz))
+        y = plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode)
+        if on_device:
+            import torch
+            torch.cuda.synchronize(dev)
+    if not gather:
+        return y, start
+    import torch
+    import torch.distributed as dist
+    t = y.tensor if on_device else torch.from_numpy(y)
+    if on_device and dist.get_backend(group) != "nccl":
+        t = torch.from_numpy(y.get())   # a host-side group carries host tensors
+    world = dist.get_world_size(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, int(t.shape[1]), group=group)
+    cmax = max(counts)
+    mine = torch.zeros((t.shape[0], cmax) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+    mine[:, :t.shape[1]] = t
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    full = torch.cat([b[:, :c] for b, c in zip(bufs, counts)], dim=1).contiguous()
+    if on_device:
+        return (DeviceArray(full) if full.is_cuda else DeviceArray.from_host(full.numpy(), device=dev)), start
+    return full.numpy(), start
 
 
 def _all_gather_channels(shard, band_min, band_max, group):

@@ -113,7 +113,12 @@ _PLAN_CACHE_SIZE = 4
 
 
 def _device_of(z):
-    return z.data.device_index if isinstance(z.data, DeviceArray) else 0
+    """Device of the signal's data; host data goes to the process's current device (one process per GPU:
+    torch.cuda.set_device(LOCAL_RANK) is what selects it)."""
+    if isinstance(z.data, DeviceArray):
+        return z.data.device_index
+    import torch
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
 
 
 def _geometry(z):
@@ -122,28 +127,33 @@ def _geometry(z):
     return len(z), nchan, npol
 
 
-def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto"):
-    """Cached pbh plan for this signal geometry (+ generated chirp)."""
+def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto", per_pol=False, dtype=None):
+    """Cached pbh plan for this signal geometry (+ generated chirp).  ``per_pol``: the uploaded chirp has one
+    row per (channel, polarisation) series, i.e. the plan is (nsample, nchan*npol, 1)."""
     nsample, nchan, npol = _geometry(z)
+    if per_pol:
+        nchan, npol = nchan * npol, 1
     dev = _device_of(z)
-    freqs = np.asarray(u.to_value(z.channel_freqs, u.Hz), dtype=np.float64).reshape(nchan)
-    coeff = dm._coeff_s_mhz2 * 1e12
-    dt = u.to_value(z.dt, u.s)
-    ref = _hz(ref_freq)
-    ckey = None if chirp is not None else (coeff, dt, freqs.tobytes(), ref)
+    dtype = np.dtype(z.dtype if dtype is None else dtype)
+    ckey = None
+    if chirp is None:
+        freqs = np.asarray(u.to_value(z.channel_freqs, u.Hz), dtype=np.float64).reshape(nchan)
+        coeff = dm._coeff_s_mhz2 * 1e12
+        dt = u.to_value(z.dt, u.s)
+        ckey = (coeff, dt, freqs.tobytes(), _hz(ref_freq))
     # (a plan is not re-entrant: the cache is per thread, so concurrent callers never share one)
-    key = (nsample, nchan, npol, crop, dev, variant, np.dtype(z.dtype).str, threading.get_ident())
+    key = (nsample, nchan, npol, crop, dev, variant, dtype.str, threading.get_ident())
     with _PLANS_LOCK:
         ent = _PLANS.pop(key, None)
     if ent is None:
-        plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant, dtype=z.dtype)
+        plan = _hip.Plan(nsample, nchan, npol, crop[0], crop[1], device=dev, variant=variant, dtype=dtype)
         ent = [plan, object()]
     plan = ent[0]
     if chirp is not None:
         plan.chirp_upload(chirp)
         ent[1] = object()
     elif ent[1] != ckey:
-        plan.chirp_generate(coeff, dt, freqs, ref)
+        plan.chirp_generate(ckey[0], ckey[1], freqs, ckey[3])
         ent[1] = ckey
     stale = []
     with _PLANS_LOCK:
@@ -175,17 +185,43 @@ def _crop_bounds(z, dm, ref_freq):
     return start, stop
 
 
-def _as_2d_chirp(chirp, z):
-    """A user chirp is (N, nchan) or (N, nchan, 1, ...) (dedispersion.py:103-105, 124)."""
-    want = (len(z), z.nchan)
-    shape = tuple(chirp.shape)
-    if shape[:2] != want or any(s != 1 for s in shape[2:]):
-        raise NotImplementedError(
-            f"chirp must have shape {want} (optionally with trailing length-1 axes); got {shape}")
-    if isinstance(chirp, DeviceArray):
-        c = DeviceArray(chirp.tensor.reshape(want)).contiguous()
-        return c if c.dtype == np.complex64 else c.astype(np.complex64)
-    return np.ascontiguousarray(np.asarray(chirp).reshape(want), dtype=np.complex64)
+def _broadcast_chirp(chirp, z):
+    """A user ``chirp=`` is multiplied into the spectrum unchecked: ``fft(z.data, axis=0) * chirp``
+    (dedispersion.py:124-125), so anything numpy can broadcast against ``z.data`` is accepted -- the documented
+    ``(N, nchan)`` / ``(N, nchan, 1...)`` forms (dedispersion.py:103-105), one row per polarisation
+    ``(N, nchan, npol)``, one row for all channels ``(N,)`` / ``(N, 1)``, a 0-d array...  (A chirp with fewer axes than
+    the signal gets length-1 axes appended first, as in the reference.)  Returns ``(rows, per_pol, dtype)``:
+    the chirp as a C-contiguous ``(N, nseries)`` array (numpy or DeviceArray) with one column per channel, or per
+    (channel, pol) series when it differs between polarisations, in the dtype of numpy's product."""
+    full = tuple(z.shape)
+    on_dev = isinstance(chirp, DeviceArray)
+    c = chirp if on_dev else np.asarray(chirp)
+    cshape = tuple(c.shape)
+    if len(cshape) > len(full):
+        raise ValueError(f"operands could not be broadcast together with shapes {full} {cshape}")
+    padded = cshape + (1,) * (len(full) - len(cshape))   # dedispersion.py:124: length-1 axes are appended, THEN numpy broadcasts
+    if any(a != 1 and a != b for a, b in zip(padded, full)):
+        raise ValueError(f"operands could not be broadcast together with shapes {full} {cshape}")
+    per_pol = any(a != 1 for a in padded[2:])
+    target = full if per_pol else full[:2] + (1,) * (len(full) - 2)
+    dtype = np.result_type(z.dtype, c.dtype)
+    if dtype not in (np.dtype(np.complex64), np.dtype(np.complex128)):
+        raise TypeError(f"the product of {z.dtype} data and a {c.dtype} chirp is {dtype}; the HIP path takes complex64/128")
+    if on_dev:
+        import torch
+        t = torch.broadcast_to(c.tensor.reshape(padded), target).to(_TORCH_OF[dtype]).reshape(full[0], -1).contiguous()
+        return DeviceArray(t), per_pol, dtype
+    rows = np.ascontiguousarray(np.broadcast_to(c.reshape(padded), target).reshape(full[0], -1), dtype=dtype)
+    return rows, per_pol, dtype
+
+
+class _TorchOf(dict):
+    def __missing__(self, key):
+        import torch
+        return {np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[np.dtype(key)]
+
+
+_TORCH_OF = _TorchOf()
 
 
 def _prepare(z, DM, ref_freq, chirp, variant, allow_series=False):
@@ -195,16 +231,19 @@ def _prepare(z, DM, ref_freq, chirp, variant, allow_series=False):
         ref_freq = z.center_freq
     _hip._dtype_code(z.dtype)  # complex64 -> float32 kernels, complex128 -> float64 kernels (as scipy.fft)
     start, stop = _crop_bounds(z, DM, ref_freq)
-    c2 = None if chirp is None else _as_2d_chirp(chirp, z)
-    plan, on_device = _plan_for(z, DM, ref_freq, (start, stop), chirp=c2, variant=variant)
+    rows, per_pol, dtype = (None, False, np.dtype(z.dtype)) if chirp is None else _broadcast_chirp(chirp, z)
+    plan, on_device = _plan_for(z, DM, ref_freq, (start, stop), chirp=rows, variant=variant, per_pol=per_pol, dtype=dtype)
+    data = z.data
+    if dtype != np.dtype(z.dtype):   # complex64 data times a complex128 chirp is complex128 in numpy: so is the result here
+        data = data.astype(dtype)
     if on_device:
         # a series-major (time-fastest) device array goes through as it is when the plan has the
         # layout-aware path (multi-pass power-of-two lengths); otherwise one contiguous copy
-        keep = (allow_series and not z.data.tensor.is_contiguous() and z.data.series_major_pitch() is not None
+        keep = (allow_series and not data.tensor.is_contiguous() and data.series_major_pitch() is not None
                 and plan.supports_series_major)
-        x = z.data if keep else z.data.contiguous()
+        x = data if keep else data.contiguous()
     else:
-        x = np.ascontiguousarray(z.data)
+        x = np.ascontiguousarray(data)
     return plan, x, start, stop
 
 
@@ -242,6 +281,11 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     """
     # a series-major device array goes through as it is when the fused tail applies (nscrunch % 64 == 0)
     plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant, allow_series=int(nscrunch) % 64 == 0)
+    if plan.nchan != z.nchan:
+        # a chirp that differs between polarisations runs as nchan*npol single-pol channels: detection needs the
+        # (channel, pol) structure back, so it is a pass of its own here
+        y = plan.dedisperse(x)   # keeps x's (nsample, nchan, npol...) trailing shape
+        return _hip.detect(y, mode=mode, nscrunch=nscrunch), start
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
 
 

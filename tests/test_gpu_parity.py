@@ -259,8 +259,8 @@ def test_arbitrary_length_stream_and_detect():
 
 def test_errors():
     zz = make_signal(orc.synthetic_block((1024, 2), 1), 1e6, 1e9)
-    with pytest.raises(NotImplementedError):
-        pb.coherent_dedispersion(zz, pb.DM(1.0), chirp=np.ones((1024, 2, 2), np.complex64))
+    with pytest.raises(ValueError):   # does not broadcast against z.data
+        pb.coherent_dedispersion(zz, pb.DM(1.0), chirp=np.ones((1024, 3), np.complex64))
 
 
 def test_full_size_properties():

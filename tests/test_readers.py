@@ -358,5 +358,5 @@ def test_reader_oracle_against_frozen_vectors():
     x = np.flip(ro.dada_samples(DATA / "stokes_ef.dada"), axis=-1).transpose(0, 2, 1)
     assert np.array_equal(x[0], g["stokes_first"]) and np.array_equal(x[-1], g["stokes_last"])
     # sanity of the data themselves: 2-bit VDIF samples take the four levels, 8-bit DADA samples are integers
-    assert set(np.unique(g["vdif_head"])) <= {np.float32(-3.3359), np.float32(-1), np.float32(1), np.float32(3.3359)}
+    assert set(np.unique(g["vdif_head"])) <= {np.float32(-3.316505), np.float32(-1), np.float32(1), np.float32(3.316505)}
     assert np.all(g["dada_head"].real == np.round(g["dada_head"].real))
