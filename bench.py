@@ -11,9 +11,11 @@ configs[2]: 64 channels of 6.25 MHz); every rank holds 8 channels x 2 pol x 2^24
 it, so per-GPU work is fixed ("weak").  Channels are independent, so there is no data-path
 collective: ranks only meet at the timing barriers.
 
-One "step" = one pbh_dedisperse call (FFT -> chirp -> IFFT -> crop) on a block already
-resident in HBM, output left resident.  Chirp generation is a per-geometry setup cost and is
-timed separately (reported as chirp_ms).
+One "step" = one call of the product's sharded entry point,
+pulsarbat_amd.shard.coherent_dedispersion_sharded (FFT -> chirp -> IFFT -> crop on this rank's
+channels with the full band's crop; at N=1 the rank holds the whole band), on a block already
+resident in HBM, output left resident and sharded.  Plan and chirp are cached per geometry after the first call;
+chirp generation is timed separately (reported as chirp_ms).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu]
   N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -61,6 +63,8 @@ def cpu_baseline():
     t0 = time.perf_counter()
     chirp = orc.chirp_from_signal(DM, shape, sr, CENTER_HZ)
     t_chirp = time.perf_counter() - t0
+    # warm-up on a 2^22-sample slice of the same block (pocketfft plan caches, page faults of the allocator), SURVEY.md 8d
+    orc.coherent_dedispersion(x[:1 << 22], DM, sr, CENTER_HZ, chirp=chirp[:1 << 22])
     t0 = time.perf_counter()
     orc.coherent_dedispersion(x, DM, sr, CENTER_HZ, chirp=chirp)
     t1 = time.perf_counter() - t0
@@ -90,7 +94,7 @@ def cpu_baseline():
     return {
         "value": nsamp / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": "oracle (numpy+scipy.fft, workers=None) on one full (2^24, 8, 2) c64 block, "
-                  "DM 56.77, chirp precomputed; %.2f s" % t1,
+                  "DM 56.77, chirp precomputed, after a warm-up call on 2^22 samples; %.2f s" % t1,
         "all_cores": {"value": nsamp / tall / 1e6, "cores": ncores, "seconds": tall},
         "series_thread_pool": None if tpool is None else {"value": nsamp / tpool / 1e6, "cores": nthreads, "seconds": tpool},
         "chirp_seconds": t_chirp, "host_cpus": ncores,
@@ -104,7 +108,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-series", action="store_true", help="skip the series-major secondary figure")
-    ap.add_argument("--gather", action="store_true", help="(multi-rank) also time the all-gather of the outputs")
+    ap.add_argument("--gather", nargs="?", const="all", default=None, choices=["all", "root"],
+                    help="(multi-rank) also time one step that ends with the gather of the outputs by direct peer writes: "
+                         "every rank gets the full band (all) or rank 0 does (root)")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--log2n", type=int, default=24, help="(debug) nsample = 2^log2n")
     ap.add_argument("--dm", type=float, default=DM, help="(debug) dispersion measure")
@@ -168,9 +174,20 @@ def main():
     x = torch.randn((nsample, NCHAN_PER_GPU, NPOL, 2), generator=gen, device="cuda",
                     dtype=torch.float32) * (2 ** -0.5)
     x = DeviceArray(torch.view_as_complex(x))
-    plan = _hip.Plan(nsample, NCHAN_PER_GPU, NPOL, start, stop, device=local_rank, variant=args.variant)
-    y = DeviceArray.empty((plan.nout, NCHAN_PER_GPU, NPOL), np.complex64, device=local_rank)
+    # this rank's shard as the product sees it: a DualPolarizationSignal of its 8 channels
+    from pulsarbat_amd import shard
+    from pulsarbat_amd.transforms.dedispersion import _plan_for
+    z_local = pb.DualPolarizationSignal(x, sample_rate=sr * u.Hz, center_freq=float(np.mean(freqs)) * u.Hz,
+                                        pol_type="linear")
+    band = dict(band_min=(CENTER_HZ - BAND_HZ / 2) * u.Hz, band_max=(CENTER_HZ + BAND_HZ / 2) * u.Hz,
+                ref_freq=CENTER_HZ * u.Hz)
 
+    def step():
+        return shard.coherent_dedispersion_sharded(z_local, dm, variant=args.variant, **band)
+
+    # the plan the entry point uses (its per-thread cache): for the chirp timing, the per-kernel profile and the info
+    plan, _ = _plan_for(z_local, dm, band["ref_freq"], (start, stop), variant=args.variant, device=local_rank)
+    assert (plan.crop_start, plan.crop_stop) == (start, stop)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan.chirp_generate(coeff, 1.0 / sr, freqs, CENTER_HZ)
@@ -183,13 +200,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    y = None
     for _ in range(args.warmup):
-        plan.dedisperse(x, out=y)
+        y = step()
     barrier()
     mark("warm-up done (first barrier includes RCCL communicator set-up)")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.dedisperse(x, out=y)
+        y = step()
     barrier()
     elapsed = time.perf_counter() - t0
     mark("timed region done")
@@ -197,23 +215,32 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same step timed with HIP events on the stream the kernels run on, one pair per step: median of >= 20
+    ev_n = max(20, args.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ev_n)]
+    for a, b in evs:
+        a.record()
+        y = step()
+        b.record()
+    torch.cuda.synchronize()
+    ev_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    event_median_ms = ev_ms[len(ev_ms) // 2]
+    y = y.data
 
     # optional: the one real exchange step of the sharded path, an all-gather of the outputs along the channel
     # axis (results are left sharded by default; the gather is timed separately)
     gather_ms = None
     if distributed and args.gather:
         try:
-            sig = pb.DualPolarizationSignal(y, sample_rate=sr * u.Hz, center_freq=float(np.mean(freqs)) * u.Hz,
-                                            pol_type="linear")
-            from pulsarbat_amd.shard import _all_gather_channels
-            lo, hi = (CENTER_HZ - BAND_HZ / 2) * u.Hz, (CENTER_HZ + BAND_HZ / 2) * u.Hz
-            _all_gather_channels(sig, lo, hi, None)
+            from pulsarbat_amd.node import ChannelGather
+            g = ChannelGather(plan.nout, NCHAN_PER_GPU, NPOL, np.complex64, local_rank, mode=args.gather)
+            g.run(plan, x)
             barrier()
             t1 = time.perf_counter()
-            full = _all_gather_channels(sig, lo, hi, None)
-            barrier()
+            g.run(plan, x)     # dedispersion + delivery of the slice to the destination block(s) + closing barrier
             gather_ms = (time.perf_counter() - t1) * 1e3
-            del full
+            g.close()
+            del g
         except Exception as exc:   # never lose the main line to the optional figure
             gather_ms = repr(exc)
 
@@ -258,6 +285,8 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": "stored: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                  "command (tools/prof.sh); not collected in this run",
                 "alg_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms}
     total_kernel_ms = sum(ms for _, ms in kern)
     path_bytes = info["alg_bytes_per_sample"] * samples_gpu  # 68 B/sample accounting figure
@@ -282,11 +311,13 @@ def main():
                        "nchan_total": nchan_total, "crop": [start, stop], "variant": info["variant"],
                        "n1": info["n1"], "n2": info["n2"], "sharding": "channels across ranks, no collective"},
             "roofline": roofline, "path_roofline": path, "chirp_ms": chirp_ms,
+            "ms_per_step_event_median": event_median_ms, "event_steps": ev_n,
+            "step": "pulsarbat_amd.shard.coherent_dedispersion_sharded (cached plan + chirp), output left sharded",
         }
         if series_major is not None:
             result["series_major_io"] = series_major
         if gather_ms is not None:
-            result["all_gather_ms"] = gather_ms
+            result["step_with_gather_ms"] = {"mode": args.gather, "ms": gather_ms}
         if world == 1 and not args.no_cpu:
             try:
                 result["cpu_baseline"] = cpu_baseline()

@@ -151,9 +151,8 @@ def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_fre
         out = type(z_local).like(z_local, y, **kw)
         return out if not gather else _all_gather_channels(out, band_min, band_max, group)
 
-    from . import _hip
     from .device import DeviceArray
-    from .transforms.dedispersion import _broadcast_chirp, _geometry
+    from .transforms.dedispersion import _broadcast_chirp, _geometry, _plan_for
     nsample, nchan, npol = _geometry(z_local)
     on_device = isinstance(z_local.data, DeviceArray)
     dev = _rank_device(z_local, device)
@@ -167,29 +166,24 @@ def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_fre
     data = z_local.data if dtype == np.dtype(z_local.dtype) else z_local.data.astype(dtype)
     x = data.contiguous() if on_device else np.ascontiguousarray(data)
     center = (band_min + band_max) / 2
-    with _hip.Plan(nsample, pchan, ppol, start, stop, device=dev, variant=variant, dtype=dtype) as plan:
-        if rows is None:
-            plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, ref_hz)
-        else:
-            plan.chirp_upload(rows)
-        if gather and on_device:
-            from .node import ChannelGather
-            mode = "root" if gather == "root" else "all"
-            g = ChannelGather(plan.nout, pchan, ppol, dtype, dev, group=group, mode=mode, root=root)
-            try:
-                full = g.run(plan, x)
-            finally:
-                g.close()
-            if full is None:   # a non-root rank of a root gather: its slice went to the root, nothing stays here
-                return None
-            n_total = g.nchan_total // (npol if per_pol else 1)
-            full = DeviceArray(full.tensor.reshape((plan.nout, n_total) + tuple(z_local.shape[2:])))
-            return type(z_local).like(z_local, full, center_freq=center, freq_align="center", **kw)
-        else:
-            y = plan.dedisperse(x)
-        if on_device:
-            import torch
-            torch.cuda.synchronize(dev)
+    # the per-thread plan cache of coherent_dedispersion, keyed on this shard's geometry, the FULL band's crop and the
+    # shard's channel frequencies: a stream of blocks re-uses plan and chirp
+    plan, _ = _plan_for(z_local, DM, ref_freq, (start, stop), chirp=rows, variant=variant, per_pol=per_pol, dtype=dtype,
+                        device=dev)
+    if gather and on_device:
+        from .node import ChannelGather
+        mode = "root" if gather == "root" else "all"
+        g = ChannelGather(plan.nout, pchan, ppol, dtype, dev, group=group, mode=mode, root=root)
+        try:
+            full = g.run(plan, x)
+        finally:
+            g.close()
+        if full is None:   # a non-root rank of a root gather: its slice went to the root, nothing stays here
+            return None
+        n_total = g.nchan_total // (npol if per_pol else 1)
+        full = DeviceArray(full.tensor.reshape((plan.nout, n_total) + tuple(z_local.shape[2:])))
+        return type(z_local).like(z_local, full, center_freq=center, freq_align="center", **kw)
+    y = plan.dedisperse(x)   # device data: asynchronous on the current stream, like every other device transform
     out = type(z_local).like(z_local, y, **kw)
     if not gather or on_device:
         return out
@@ -205,21 +199,14 @@ def dedisperse_detect_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, m
     small all-gather over RCCL (device data) or gloo (host data)."""
     if not isinstance(z_local, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
-    from . import _hip
     from .device import DeviceArray
-    from .transforms.dedispersion import _geometry
+    from .transforms.dedispersion import _plan_for
     start, stop = _full_band_crop(DM, len(z_local), z_local.sample_rate, band_min, band_max, ref_freq)
-    freqs = np.asarray(u.to_value(z_local.channel_freqs, u.Hz), dtype=np.float64)
-    nsample, nchan, npol = _geometry(z_local)
     on_device = isinstance(z_local.data, DeviceArray)
     dev = _rank_device(z_local, device)
     x = z_local.data.contiguous() if on_device else np.ascontiguousarray(z_local.data)
-    with _hip.Plan(nsample, nchan, npol, start, stop, device=dev, variant=variant, dtype=z_local.dtype) as plan:
-        plan.chirp_generate(DM._coeff_s_mhz2 * 1e12, u.to_value(z_local.dt, u.s), freqs, u.to_value(ref_freq, u.Hz))
-        y = plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode)
-        if on_device:
-            import torch
-            torch.cuda.synchronize(dev)
+    plan, _ = _plan_for(z_local, DM, ref_freq, (start, stop), variant=variant, device=dev)
+    y = plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode)
     if not gather:
         return y, start
     import torch

@@ -127,13 +127,14 @@ def _geometry(z):
     return len(z), nchan, npol
 
 
-def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto", per_pol=False, dtype=None):
+def _plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto", per_pol=False, dtype=None, device=None):
     """Cached pbh plan for this signal geometry (+ generated chirp).  ``per_pol``: the uploaded chirp has one
-    row per (channel, polarisation) series, i.e. the plan is (nsample, nchan*npol, 1)."""
+    row per (channel, polarisation) series, i.e. the plan is (nsample, nchan*npol, 1).  ``crop`` need not be the
+    signal's own: a rank of a channel-sharded job passes the full band's (shard.py)."""
     nsample, nchan, npol = _geometry(z)
     if per_pol:
         nchan, npol = nchan * npol, 1
-    dev = _device_of(z)
+    dev = _device_of(z) if device is None else int(device)
     dtype = np.dtype(z.dtype if dtype is None else dtype)
     ckey = None
     if chirp is None:
