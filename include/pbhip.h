@@ -145,6 +145,12 @@ int pbh_pol_basis(int device, void* hip_stream, int dtype, const void* in_dev, v
  * (sample, channel).  delay: host array of non-negative sample offsets.                                   */
 int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
                    int unit_words, const int64_t* delay);
+/* The same gather on series-major device arrays (time fastest: series q = chan*series_per_chan + j starts at
+ * base + q*pitch; pitches in 4-byte words; an element of a series is unit_words = 1, 2 or 4 words): one shifted
+ * contiguous copy per series, out[q][t] = in[q][t + delay[chan]].                                            */
+int pbh_incoherent_series(int device, void* hip_stream, const void* in_dev, int64_t in_pitch_words, void* out_dev,
+                          int64_t out_pitch_words, int64_t nout, int nchan, int series_per_chan, int unit_words,
+                          const int64_t* delay);
 
 /* pbh_fft_c2c and pbh_stft keep, per calling thread, up to two Bluestein and two multi-pass transform plans
  * (twiddle tables and a workspace the size of the data) for reuse by the next call of the same shape.
@@ -193,6 +199,11 @@ int pbh_dedisperse_slice(pbh_plan* plan, const void* in_dev, void* out_dev, int6
  * pbh_dedisperse_slice.  The exporter must keep the buffer alive until every importer has called
  * pbh_node_release; a host-side barrier after the writers' streams have drained makes the data visible
  * to the owner.  Replaces the reference's in-process gather of chunk results (core.py:298-309).          */
+/* freq_shift (pulsarbat/transforms/transforms.py:337-361): out = IFFT(H * FFT(x[n, s] * exp(2 pi i ft[s] n))) with the
+ * plan's filter H (pbh_chirp_special mode 1: the out-of-band mask).  ft: host array of nchan*npol shifts in cycles per
+ * sample.  Device-resident C-contiguous in / out; the mixer is folded into the plan's de-interleave pass where it has
+ * one (no copy of the caller's data, no separate mixing pass), else it is one out-of-place pass.                    */
+int pbh_dedisperse_mix(pbh_plan* plan, const void* in_dev, void* out_dev, const double* ft);
 /* pbh_place: 2-D copy between sample-major device arrays (nrow rows of ncol complex elements, row pitches in
  * elements) -- the push of a rank's channel slice into a peer's full-band block in the all-gather form.       */
 int pbh_place(int device, void* hip_stream, int dtype, const void* src_dev, int64_t src_row_elems, void* dst_dev,
@@ -286,6 +297,17 @@ int pbh_fft_c2c(int device, void* hip_stream, int dtype, const void* in, void* o
  * Any nperseg >= 1; powers of two up to one tile run a single fused kernel.                               */
 int pbh_stft(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nseg, int nperseg,
              int nchan, int inner, int inverse, int in_loc, int out_loc);
+
+/* contrib.stft followed by coherent_dedispersion -- the reference's typical channelise-then-dedisperse pipeline
+ * (pulsarbat/contrib/misc.py:41-55, then transforms/dedispersion.py:118-133) -- in one call.  `plan` is the
+ * dedispersion plan of the CHANNELISED block: nsample = nseg, nchan = nchan_in*nperseg, npol = inner elements per
+ * channel, chirp set for the channelised signal's channel frequencies; in_dev is the device-resident C-contiguous
+ * (nseg*nperseg, nchan_in, inner) block the channeliser reads.  out: (stop-start, nchan_in*nperseg, inner), sample-major
+ * or series-major as in pbh_dedisperse_layout.  Where the geometry allows (complex64, nperseg = 2^m in [32, 1024],
+ * nseg beyond one tile) the channeliser writes series-major into the plan's work buffer and the dedispersion starts
+ * at its column pass: the channelised block makes one HBM round trip less.  Asynchronous on the plan's stream.     */
+int pbh_stft_dedisperse(pbh_plan* plan, const void* in_dev, int nperseg, int nchan_in, void* out_dev, int out_layout,
+                        int64_t out_pitch);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Runs the plan's kernel sequence `iters` times on device-resident in/out with hipEvents between the

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pbh_pol_basis": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pbh_incoherent": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.POINTER(C.c_int64)]),
+    "pbh_incoherent_series": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "pbh_chirp_function": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int]),
     "pbh_trim": (C.c_int, []),
@@ -88,6 +90,7 @@ SIGNATURES = {
                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "pbh_dedisperse_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "pbh_place": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "pbh_node_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pbh_node_free": (C.c_int, [C.c_int, C.c_void_p]),
@@ -108,6 +111,7 @@ SIGNATURES = {
                               C.c_int, C.c_int]),
     "pbh_stft": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_int]),
+    "pbh_stft_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "pbh_copy_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
@@ -388,6 +392,52 @@ class Plan:
         _check(lib().pbh_dedisperse(self._h, pin, pout, lin, lout))
         return out
 
+    def stft_dedisperse(self, x, nperseg, out_layout="sample"):
+        """``coherent_dedispersion(stft(x, nperseg))`` in one call (``pbh_stft_dedisperse``): ``x`` is the device-resident
+        ``(nseg*nperseg, nchan_in, ...)`` block in front of the channeliser, this plan the dedispersion plan of the
+        channelised block ``(nseg, nchan_in*nperseg, ...)``."""
+        from .device import DeviceArray
+        if not isinstance(x, DeviceArray):
+            raise TypeError("stft_dedisperse takes a device-resident input")
+        nperseg = int(nperseg)
+        nchan_in = x.shape[1]
+        inner = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+        if x.shape[0] != self.nsample * nperseg or nchan_in * nperseg != self.nchan or inner != self.npol or x.dtype != self.dtype:
+            raise ValueError(f"input {tuple(x.shape)} {x.dtype} does not match a ({self.nsample}, {self.nchan}, {self.npol}) "
+                             f"plan with nperseg = {nperseg}")
+        self._sync_stream()
+        oshape = (self.nout, self.nchan) + tuple(x.shape[2:])
+        if self.nout == 0:
+            return DeviceArray.empty(oshape, self.dtype, device=self.device)
+        if out_layout == "series":
+            out = DeviceArray.empty_series_major(oshape, self.dtype, device=self.device, align_start=self.crop_start)
+            pitch = out.series_major_pitch()
+        elif out_layout == "sample":
+            out, pitch = DeviceArray.empty(oshape, self.dtype, device=self.device), 0
+        else:
+            raise ValueError("out_layout must be 'sample' or 'series'")
+        _check(lib().pbh_stft_dedisperse(self._h, C.c_void_p(x.contiguous().data_ptr()), nperseg, int(nchan_in),
+                                         C.c_void_p(out.raw_ptr()), int(out_layout == "series"), int(pitch)))
+        return out
+
+    def dedisperse_mix(self, x, ft):
+        """``IFFT(H * FFT(x * exp(2 pi i ft n)))`` on a C-contiguous device array, ``ft`` per series in cycles per sample
+        (freq_shift: the mixer rides in the plan's de-interleave pass, ``pbh_dedisperse_mix``)."""
+        from .device import DeviceArray
+        if not isinstance(x, DeviceArray):
+            raise TypeError("dedisperse_mix takes a device-resident input")
+        self._check_in(x)
+        self._sync_stream()
+        a = np.ascontiguousarray(ft, dtype=np.float64)
+        if a.shape != (self.nchan * self.npol,):
+            raise ValueError("ft must have one entry per series")
+        out = DeviceArray.empty((self.nout,) + tuple(x.shape[1:]), self.dtype, device=self.device)
+        if self.nout == 0:
+            return out
+        _check(lib().pbh_dedisperse_mix(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                        a.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def dedisperse_slice(self, x, out_ptr, row_elems, col_offset):
         """Dedisperse device array ``x`` and write the ``(nout, nchan, npol)`` result as columns
         ``[col_offset, col_offset + nchan*npol)`` of the sample-major array at device pointer ``out_ptr`` whose rows
@@ -617,6 +667,26 @@ def incoherent(x_dev, delays, nout):
     _check(lib().pbh_incoherent(x_dev.device_index, _stream_ptr(x_dev.device_index), C.c_void_p(x_dev.data_ptr()),
                                 C.c_void_p(out.data_ptr() if nout > 0 else x_dev.data_ptr()), int(nout), int(nchan),
                                 int(unit), d.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
+
+
+def incoherent_series(x_dev, delays, nout):
+    """The same gather on a series-major device array (time fastest): one shifted contiguous copy per series."""
+    from .device import DeviceArray
+    pitch = x_dev.series_major_pitch()
+    if pitch is None:
+        raise ValueError("incoherent_series needs a series-major device array")
+    nchan = x_dev.shape[1]
+    inner = int(np.prod(x_dev.shape[2:])) if x_dev.ndim > 2 else 1
+    words = x_dev.tensor.element_size() // 4
+    if words not in (1, 2, 4):
+        raise TypeError("elements must be 4, 8 or 16 bytes")
+    d = np.ascontiguousarray(delays, dtype=np.int64)
+    out = DeviceArray.empty_series_major((int(nout),) + tuple(x_dev.shape[1:]), x_dev.dtype, device=x_dev.device_index)
+    if nout > 0:
+        _check(lib().pbh_incoherent_series(x_dev.device_index, _stream_ptr(x_dev.device_index), C.c_void_p(x_dev.raw_ptr()),
+                                           int(pitch) * words, C.c_void_p(out.raw_ptr()), int(out.series_major_pitch()) * words,
+                                           int(nout), int(nchan), inner, words, d.ctypes.data_as(C.POINTER(C.c_int64))))
     return out
 
 

@@ -16,7 +16,7 @@ from .. import _hip
 from ..core import BasebandSignal
 from ..device import DeviceArray
 
-__all__ = ["stft", "istft"]
+__all__ = ["stft", "istft", "stft_dedisperse"]
 
 
 def _data(z):
@@ -46,3 +46,48 @@ def istft(z, /, window="boxcar", nperseg=256, noverlap=0, nfft=None):
     nperseg = int(nperseg)
     x = _hip.stft(_data(z), nperseg, inverse=True)
     return type(z).like(z, x, sample_rate=z.sample_rate * nperseg, freq_align="center")
+
+
+def stft_dedisperse(z, DM, /, *, nperseg=256, ref_freq=None, variant="auto"):
+    """``coherent_dedispersion(stft(z, nperseg=nperseg), DM, ref_freq=ref_freq)`` -- the channelise-then-dedisperse
+    pipeline (misc.py:41-55 followed by transforms/dedispersion.py:118-133) -- as ONE call of the HIP library
+    (``pbh_stft_dedisperse``) for device-resident signals: the channeliser writes its output series-major into the
+    dedispersion's work buffer, so the channelised block is neither stored in the reference layout nor de-interleaved
+    again.  Same result, metadata included, as the two calls; signals on the host, or geometries the fused kernel does
+    not cover, run the two steps one after the other."""
+    import math
+    from ..transforms.dedispersion import _plan_for, coherent_dedispersion
+    if not isinstance(z, BasebandSignal):
+        raise ValueError("z must be a BasebandSignal.")
+    nperseg = int(nperseg)
+    if not isinstance(z.data, DeviceArray) or z.data.dtype != np.complex64 or nperseg < 2:
+        return coherent_dedispersion(stft(z, nperseg=nperseg), DM, ref_freq=ref_freq, variant=variant)
+    z = z[: len(z) - len(z) % nperseg, :]
+    nseg = len(z) // nperseg
+    # the channelised signal's metadata (sample rate, channel grid, start time) through the container's own rules, on a
+    # one-sample placeholder: the arrays themselves never exist in the reference layout
+    falign = "center" if nperseg % 2 else "bottom"
+    shape1 = (1, z.shape[1] * nperseg) + tuple(z.shape[2:])
+    meta = type(z).like(z, np.zeros(shape1, dtype=z.dtype), sample_rate=z.sample_rate / nperseg, freq_align=falign)
+    ref = meta.center_freq if ref_freq is None else ref_freq
+    top = float(DM.sample_delay(meta.max_freq, ref, meta.sample_rate))
+    bot = float(DM.sample_delay(meta.min_freq, ref, meta.sample_rate))
+    start, stop = math.ceil(-min(0, top, bot)), nseg - math.ceil(max(0, top, bot))
+
+    class _Geom:   # what _plan_for reads of a signal: geometry, channel grid, sampling, dtype, data (for the device)
+        shape = (nseg,) + shape1[1:]
+        ndim = len(shape1)
+        dtype = z.dtype
+        data = z.data
+        channel_freqs = meta.channel_freqs
+        dt = meta.dt
+
+        def __len__(self):
+            return nseg
+
+    plan, _ = _plan_for(_Geom(), DM, ref, (start, stop), variant=variant)
+    y = plan.stft_dedisperse(z.data, nperseg)
+    kw = {}
+    if z.start_time is not None:
+        kw["start_time"] = z.start_time + start / meta.sample_rate
+    return type(z).like(z, y, sample_rate=meta.sample_rate, freq_align=falign, **kw)

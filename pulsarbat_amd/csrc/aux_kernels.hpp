@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_deinterleave(const cf* __restrict__ in,
 // planar [s][t] -> (stop-start, S) interleaved, keeping t in [start, stop)
 // (opitch: elements between consecutive output rows; S for a compact output, more when the rows are a
 //  channel slice of a wider array -- the multi-GPU gather writes a rank's channels into the full-band block)
+// (dly: optional per-series time offsets, series s is read at t + dly[s] -- the shifted gather of incoherent dedispersion)
 __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in, cf* __restrict__ out,
                                                       int64_t start, int64_t stop, int S, int TN,
-                                                      int64_t plane, int64_t opitch) {
+                                                      int64_t plane, int64_t opitch, const int64_t* __restrict__ dly = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_reinterleave(const cf* __restrict__ in,
     const int cnt = rows * S;
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
         int s = e / rows, n = e - s * rows;
-        lds[n * (S + 1) + s] = in[(int64_t)s * plane + t0 + n];
+        lds[n * (S + 1) + s] = in[(int64_t)s * plane + t0 + n + (dly ? dly[s] : 0)];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -508,9 +509,20 @@ __global__ __launch_bounds__(256) void k_stft_out(const cf* __restrict__ in, cf*
 // Power-of-two S fast paths: a tile is TN = 4096/S time samples (32 KiB), 256 threads, each thread
 // moves 8 float4 (two complex) per side with all loads issued before the first use -- the shape the
 // streaming-copy calibration (tools/micro/membench.hip) found fastest on MI355X.
-template <int S>
+// x * exp(2 pi i ft n): float64 phase reduced to one revolution, then the hardware's cos / sin (max error 1.4e-7, the
+// size of the complex64 rounding the reference applies to its phasor, transforms.py:346)
+__device__ __forceinline__ cf mix_sample(cf x, double ft, int64_t n) {
+    const double phi = ft * (double)n;
+    const float fr = (float)(phi - rint(phi));
+    return cmul(x, make_cf(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr)));
+}
+
+// (MIX: freq_shift's mixer folded into the pass -- every sample is multiplied by exp(2 pi i ft[s] n) on its way
+//  through, which saves the copy and the mixing pass in front of the pipeline)
+template <int S, bool MIX = false>
 __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
-                                                         int64_t N, int64_t plane, int64_t nvalid) {
+                                                         int64_t N, int64_t plane, int64_t nvalid,
+                                                         const double* __restrict__ ft = nullptr) {
     constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;  // 8 float4 per thread
     __shared__ cf lds[S * LD];
     const int64_t n0 = (int64_t)blockIdx.x * TN;
@@ -551,15 +563,21 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
     for (int j = 0; j < NV; ++j) {
         const int pidx = threadIdx.x + 256 * j;
         const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
-        const cf a = lds[s * LD + n], b = lds[s * LD + n + 1];
+        cf a = lds[s * LD + n], b = lds[s * LD + n + 1];
+        if constexpr (MIX) {
+            const double f = ft[s];
+            a = mix_sample(a, f, n0 + n);
+            b = mix_sample(b, f, n0 + n + 1);
+        }
         *reinterpret_cast<float4*>(out + (int64_t)s * plane + n0 + n) = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
 // planar [s][t] -> (stop-start, S); the tail tile is handled by the generic kernel
-template <int S, bool PITCHED = false>
+template <int S, bool PITCHED = false, bool SHIFTED = false>
 __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
-                                                         int64_t start, int64_t plane, int64_t opitch) {
+                                                         int64_t start, int64_t plane, int64_t opitch,
+                                                         const int64_t* __restrict__ dly = nullptr) {
     constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;
     __shared__ cf lds[S * LD];
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
@@ -569,6 +587,7 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
         const int pidx = threadIdx.x + 256 * j;
         const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
         const cf* p = in + (int64_t)s * plane + t0 + n;
+        if constexpr (SHIFTED) p += dly[s];   // (odd shifts break the 16-byte alignment: the loads stay 8 bytes wide)
         a[j] = p[0];
         b[j] = p[1];
     }
@@ -1195,6 +1214,16 @@ __global__ __launch_bounds__(256) void k_incoherent(const T* __restrict__ in, T*
         if (eo[j] >= 0) out[eo[j]] = v[j];
 }
 #endif  // !PBH_F64
+
+// series-major (time fastest) form of the same gather: out[s][t] = in[s][t + dly[s / per]], every series one contiguous run
+template <typename T>
+__global__ __launch_bounds__(256) void k_shift_rows(const T* __restrict__ in, int64_t ipitch, T* __restrict__ out, int64_t opitch,
+                                                    const int64_t* __restrict__ dly, int per, int64_t nout) {
+    const int s = blockIdx.y;
+    const T* src = in + (int64_t)s * ipitch + dly[s / per];
+    T* dst = out + (int64_t)s * opitch;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nout; t += (int64_t)gridDim.x * blockDim.x) dst[t] = src[t];
+}
 
 // ---- polarisation basis change (pulsarbat/core.py:882-928) on (n, nchan, 2) data --------------------------------
 // to_circular: L = (X - iY)/sqrt2, R = (X + iY)/sqrt2;   to_linear: X = (L + R)/sqrt2, Y = i(L - R)/sqrt2

@@ -353,6 +353,8 @@ struct RowParams {
     int N1, npol;
     int perm_w;        // chirp row order (see ChirpParams::perm_w); 8 selects k_row2
     unsigned* counter; // SP = 2: dynamic tile hand-out (zeroed before the launch); null = static stride
+    int cdiv = 1;      // rows of one tile that share a chirp row: npol when the rows of a tile are consecutive SERIES (N1 = 1,
+                       // one-tile blocks with many series), 1 when they are consecutive k1 of one series
     int cP = 1;        // the chirp rows are stored in the order of a column transform split cP x (N1/cP) while the data rows
                        // are in natural k1 order (one row per tile only): row k1 of the chirp is at (k1 % cP)*(N1/cP) + k1/cP
 #ifdef PBH_DIAGNOSTIC
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     const int tid = threadIdx.x;
     const int tau = tid % MR, f = tid / MR;
     const int voff = (f * M + tau) * (int)sizeof(cf);
+    const int cvoff = ((f / p.cdiv) * M + tau) * (int)sizeof(cf);   // chirp row of tile row f
     const int64_t ntile = (p.nrows + FR - 1) / FR;
 
     cf w[tw_seeds_or1(M, R)];
@@ -465,14 +468,14 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
                         __builtin_amdgcn_sched_barrier(0x38E);
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
-                            if (cnt < R) { c[cnt] = buf_load(rc, voff, cnt * STEP); ++cnt; }
+                            if (cnt < R) { c[cnt] = buf_load(rc, cvoff, cnt * STEP); ++cnt; }
                         __builtin_amdgcn_sched_barrier(0x38E);
                     }
                 };
                 fft_tile<M, 1, R, -1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
 #pragma unroll
                 for (int k = 0; k < R; ++k)
-                    if (cnt < R) { c[cnt] = buf_load(rc, voff, cnt * STEP); ++cnt; }
+                    if (cnt < R) { c[cnt] = buf_load(rc, cvoff, cnt * STEP); ++cnt; }
                 if (tid == 0) slot[0] = fetched;
             } else if constexpr (SP && NST >= 2) {
                 // chirp row requested during the first NST-1 stages (consumed right after the last one)
@@ -480,14 +483,14 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
                     constexpr int ST = decltype(st)::value;
                     if constexpr (std::is_same<decltype(q), ic<-1>>::value && ST < NST - 1) {
 #pragma unroll
-                        for (int i = ST * R / (NST - 1); i < (ST + 1) * R / (NST - 1); ++i) c[i] = buf_load(rc, voff, i * STEP);
+                        for (int i = ST * R / (NST - 1); i < (ST + 1) * R / (NST - 1); ++i) c[i] = buf_load(rc, cvoff, i * STEP);
                     }
                 };
                 fft_tile<M, 1, R, -1, 1, true, false, false>(v, lds, tau, f * M, w, hk);
             } else {
 #pragma unroll
                 for (int i = 0; i < R; ++i)
-                    c[i] = (ABL == 2 || ABL == 3 || ABL == 5) ? make_cf(RC(0.999), RC(0.001) * i) : buf_load(rc, voff, i * STEP);
+                    c[i] = (ABL == 2 || ABL == 3 || ABL == 5) ? make_cf(RC(0.999), RC(0.001) * i) : buf_load(rc, cvoff, i * STEP);
                 if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
             }
             stamp(2);
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         } else {
             fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, voff, i * STEP));
+            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], buf_load(rc, cvoff, i * STEP));
         }
 
         const int64_t tn = SP == 2 ? tnx : t + gridDim.x;
@@ -944,6 +947,74 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
         const bool keep = valid && row >= p.crop_start && row < p.crop_stop;
         const int off = keep ? (int)((lane_seg + (row - p.crop_start) * p.S + qq) * sizeof(cf)) : oob;
         buf_store(ro, off, 0, v[i]);
+    }
+}
+
+// ---- contrib.stft written series-major: the channeliser in front of coherent_dedispersion ----------------------------
+// stft -> coherent_dedispersion is the typical pipeline: the channelised block is "hundreds of
+// narrow series" that the dedispersion's first pass would de-interleave again.  This kernel writes the channeliser's
+// output straight into the dedispersion plan's planar work buffer (series (c*M + shifted k)*E + e at q'*plane, time =
+// segment index), so the dedispersion starts at its column pass: one full read + write of the block less.
+// A tile is M (bins) x G (consecutive segments) x SB (a subset of the input's series), G*SB*M = 2^14 points: with
+// G >= 16 every (series', bin) row receives >= 128 contiguous bytes per tile.  The G*SB column FFTs are interleaved in
+// LDS as in k_small; after the last stage the outputs take one more trip through LDS to put the segment index on the
+// lanes.  Sibling tiles (the other series subsets of the same segments, which share the input's 128-byte lines) are
+// adjacent in blockIdx.x.
+struct StftPlanarParams {
+    const cf* in;      // (nseg*M, S) sample-major
+    cf* out;           // planar: series' q' = (c*M + ((k + M/2) % M))*E + e at q'*plane + segment
+    const cf* tw16k;
+    int64_t plane;
+    int S, E;          // series of the input (nchan*E), inner elements per channel
+    int SB, G;         // series per tile, segments per tile (SB*G = tile/M)
+    real scale;        // 1/M
+};
+
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_stft_planar(StftPlanarParams p) {
+    constexpr int F = kTilePoints / M;
+    constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;
+    constexpr int NT = kTilePoints / R;      // threads
+    static_assert(F <= NT && F >= 16, "k_stft_planar: segment length out of range for this tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int f = tid % F, tau = tid / F;
+    const int j = f % p.SB, sl = f / p.SB;
+    const int q0 = blockIdx.x * p.SB;
+    const int64_t g0 = (int64_t)blockIdx.y * p.G;
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+
+    const rsrc_t ri = make_rsrc(p.in + (g0 * M) * (int64_t)p.S + q0, (uint32_t)(((int64_t)p.G * M * p.S - q0) * (int64_t)sizeof(cf)));
+    const int voff = (int)(((int64_t)sl * M * p.S + (int64_t)tau * p.S + j) * (int64_t)sizeof(cf));
+    const int step = MR * p.S * (int)sizeof(cf);
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff, i * step);
+    fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
+    __syncthreads();   // every wave is done reading the last exchange
+    // bin k = tau + i*MR of column (sl, j)  ->  staging slot (k*SB + j)*G + sl
+#pragma unroll
+    for (int i = 0; i < R; ++i) lds[((tau + i * MR) * p.SB + j) * p.G + sl] = v[i];
+    __syncthreads();
+    // thread tid, round i: slot tid + i*NT = (k*SB + jj)*G + ss with ss fastest across lanes.  NT is a multiple of
+    // F = SB*G, so ss and jj are the thread's own and only the bin advances, by NT/F per round: no division in the loop
+    {
+        const int ss = tid % p.G, rest = tid / p.G;
+        const int jj = rest % p.SB, k0 = rest / p.SB;
+        const int q = q0 + jj;
+        const int c = q / p.E, e = q - c * p.E;
+        cf* base = p.out + ((int64_t)c * M * p.E + e) * p.plane + g0 + ss;
+        const int64_t kstep = (int64_t)p.E * p.plane;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int k = k0 + i * (NT / F);
+            const cf x = lds[tid + i * NT];
+            base[(int64_t)(k ^ (M / 2)) * kstep] = make_cf(x.x * p.scale, x.y * p.scale);
+        }
     }
 }
 

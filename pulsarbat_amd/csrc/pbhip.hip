@@ -23,6 +23,7 @@
 #define pbh_pol_basis PBH_FN(pol_basis)
 #define pbh_decimate2 PBH_FN(decimate2)
 #define pbh_incoherent PBH_FN(incoherent)
+#define pbh_incoherent_series PBH_FN(incoherent_series)
 #define pbh_transfer PBH_FN(transfer)
 #define pbh_decode PBH_FN(decode)
 #define pbh_trim PBH_FN(trim)
@@ -31,6 +32,7 @@
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_slice PBH_FN(dedisperse_slice)
+#define pbh_dedisperse_mix PBH_FN(dedisperse_mix)
 #define pbh_place PBH_FN(place)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
@@ -142,6 +144,7 @@ struct pbh_plan {
     double2* tw_lo = nullptr;
     int tw_shift = 0;
     double* chan_freq = nullptr;
+    double* mix_ft = nullptr;   // per-series mixer frequencies of pbh_dedisperse_mix
     // Bluestein (nsample not a power of two, or < 32): two runs of a power-of-two sub-plan
     bool plain_fft = false;     // plan backs pbh_fft_c2c: Bluestein ring for every length, no chirp buffer
     int64_t bsL = 0;            // ring length, power of two >= 2N-1; 0 = not a Bluestein plan
@@ -425,8 +428,20 @@ static int launch_reint_blk(const cf* work, cf* out, int64_t start, int64_t stop
 }
 
 // nvalid: input time samples that exist (the rest of the N is zero padding; N for an ordinary call)
-static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t nvalid, hipStream_t st, int64_t plane = 0) {
+// the de-interleave pass can carry freq_shift's mixer (mix_ft: device array of S per-series shifts in cycles per sample)
+static bool deint_can_mix(int S, int64_t N) {
+#ifdef PBH_F64
+    (void)S; (void)N;
+    return false;
+#else
+    return blk_series(S, N) == 0 && (S & (S - 1)) == 0 && S >= 2 && S <= 128 && N % tr_rows(S) == 0;
+#endif
+}
+static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t nvalid, hipStream_t st, int64_t plane = 0,
+                               const double* mix_ft = nullptr) {
     if (plane <= 0) plane = N;   // elements between consecutive series of the planar side
+    if (mix_ft && !deint_can_mix(S, N)) return fail(PBH_ERR_STATE, "this de-interleave pass cannot carry the mixer");
+    if (!mix_ft)
     switch (blk_series(S, N)) {
         case 4: return launch_deint_blk<4>(in, work, N, S, plane, nvalid, st);
         case 8: return launch_deint_blk<8>(in, work, N, S, plane, nvalid, st);
@@ -439,7 +454,8 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
     if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
-#define X(s) case s: hipLaunchKernelGGL(k_deinterleave_p2<s>, dim3(grid), dim3(256), 0, st, in, work, N, plane, nvalid); break;
+#define X(s) case s: if (mix_ft) hipLaunchKernelGGL((k_deinterleave_p2<s, true>), dim3(grid), dim3(256), 0, st, in, work, N, plane, nvalid, mix_ft); \
+                     else hipLaunchKernelGGL((k_deinterleave_p2<s, false>), dim3(grid), dim3(256), 0, st, in, work, N, plane, nvalid, mix_ft); break;
             X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
         }
@@ -456,11 +472,11 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
 // opitch: elements between output rows (0 = compact, S); pitched rows (a channel slice of a wider array) are
 // written by the power-of-two row transposes and the generic kernel only -- slice_fast_ok()
 static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane,
-                               hipStream_t st, int64_t opitch = 0) {
+                               hipStream_t st, int64_t opitch = 0, const int64_t* dly = nullptr) {
     if (stop <= start) return PBH_OK;
     const bool pitched = opitch > 0 && opitch != S;
     if (!pitched) opitch = S;
-    if (!pitched)
+    if (!pitched && !dly)
     switch (blk_series(S, plane)) {
         case 4: return launch_reint_blk<4>(work, out, start, stop, S, plane, st);
         case 8: return launch_reint_blk<8>(work, out, start, stop, S, plane, st);
@@ -471,12 +487,13 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     const int TN = tr_rows(S);
     int64_t done = 0;
 #ifndef PBH_F64
-    if ((S & (S - 1)) == 0 && S <= 128 && !(pitched && (S < 2 || (opitch & 1) || (reinterpret_cast<uintptr_t>(out) & 15)))) {
+    if ((S & (S - 1)) == 0 && S <= 128 && !((pitched || dly) && (S < 2 || (opitch & 1) || (reinterpret_cast<uintptr_t>(out) & 15)))) {
         const int64_t full = (stop - start) / TN;
         if (full > 0) {
             switch (S) {
-#define X(s) case s: if (pitched) hipLaunchKernelGGL((k_reinterleave_p2<s, true>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch); \
-                     else hipLaunchKernelGGL((k_reinterleave_p2<s, false>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch); break;
+#define X(s) case s: if (dly) hipLaunchKernelGGL((k_reinterleave_p2<s, true, true>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch, dly); \
+                     else if (pitched) hipLaunchKernelGGL((k_reinterleave_p2<s, true>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch, dly); \
+                     else hipLaunchKernelGGL((k_reinterleave_p2<s, false>), dim3((unsigned)full), dim3(256), 0, st, work, out, start, plane, opitch, dly); break;
                 X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128)
 #undef X
             }
@@ -488,7 +505,7 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     if (start + done < stop) {  // tail (or everything, for other S) through the generic kernel
         const int64_t s2 = start + done;
         hipLaunchKernelGGL(k_reinterleave, dim3((unsigned)((stop - s2 + TN - 1) / TN)), dim3(256),
-                           (size_t)TN * (S + 1) * sizeof(cf), st, work, out + done * opitch, s2, stop, S, TN, plane, opitch);
+                           (size_t)TN * (S + 1) * sizeof(cf), st, work, out + done * opitch, s2, stop, S, TN, plane, opitch, dly);
         HIPCHECK(hipGetLastError());
     }
     return PBH_OK;
@@ -584,9 +601,24 @@ struct IoLayout {
     int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
     int64_t in_pitch = 0, out_pitch = 0;
     int64_t in_valid = -1;   // sample-major input: time samples present (the rest of nsample is zero padding); -1 = all
+    const double* mix_ft = nullptr;   // sample-major input: per-series mixer frequencies (device), applied by the de-interleave pass
     int64_t out_row_elems = 0;   // sample-major output: elements between consecutive rows (0 = compact, S): the rows are a
                                  // channel slice of a wider (nout, nchan_total, npol) array (pbh_dedisperse_slice)
 };
+
+// One-tile plans (nsample <= 2^tile) whose blocks have many series run as layout pass + planar row pass + layout pass
+// instead of the single interleaved kernel (build_steps); needs the planar work buffer (allocated at plan creation).
+static bool single_planar_ok(const pbh_plan* p) {
+    static const int mode = [] { const char* e = getenv("PBH_SINGLE_PLANAR"); return e ? atoi(e) : 1; }();
+    if (!mode || p->N1 != 1 || p->bsL || p->plain_fft || !is_pow2(p->N)) return false;
+    const int64_t M = p->N;
+    if (M < 1024 || M > kTilePoints) return false;                  // the planar row kernels' lengths (FOR_ROW_M)
+    const int FR = (int)(kTilePoints / M);
+    if (FR > 1 && ((p->npol & (p->npol - 1)) != 0 || p->npol > FR)) return false;   // rows of a tile share chirp rows pol by pol
+    // worth it from a few MiB on (below that the one-kernel form wins on launch count), and needed beyond the
+    // one-kernel form's 2-GiB addressing limit
+    return mode == 2 || (int64_t)p->S * M >= (1LL << 21);
+}
 
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
                                      IoLayout io = IoLayout()) {
@@ -637,6 +669,30 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         }});
         return steps;
     }
+    if (p->N1 == 1 && p->work && single_planar_ok(p) && !tail.out && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR &&
+        io.out_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
+        // One-tile blocks with many series (what a channeliser with long segments hands over: 2^14 samples x thousands of
+        // narrow channels).  k_small would read 8-byte pieces of every 128-byte input line once per series; here the two
+        // layout passes move full lines and the transform runs on contiguous rows of the planar copy.
+        const int64_t N = p->N, start = p->start, stop = p->stop;
+        const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
+        const int M = (int)N, FR = kTilePoints / M;
+        cf* work = p->work;
+        unsigned* ctr0 = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+        const double* mft = io.mix_ft;
+        steps.push_back({"k_deinterleave", [=](hipStream_t st) {
+            HIPCHECK(hipMemsetAsync(ctr0, 0, kCounterBytes, st));
+            return launch_deinterleave(in, work, N, S, nvalid, st, 0, mft);
+        }});
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S, 1, p->npol, 0, ctr0 + 2};
+        rp.cdiv = FR > 1 ? p->npol : 1;
+        steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(M, rp, st); }});
+        const int64_t orow = io.out_row_elems;
+        steps.push_back({"k_reinterleave", [=](hipStream_t st) {
+            return launch_reinterleave(work, out, start, stop, S, N, st, orow);
+        }});
+        return steps;
+    }
     if (p->N1 == 1) {
         SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, (real)1};
         const int M = (int)p->N;
@@ -677,10 +733,12 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
                 return launch_deint_radix(S, Pf, in, work, N, N2, N1, nvalid, st);
             }});
-        } else if (!in_sm)
+        } else if (!in_sm) {
+            const double* mft = io.mix_ft;
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
-                return launch_deinterleave(in, work, N, S, nvalid, st);
+                return launch_deinterleave(in, work, N, S, nvalid, st, 0, mft);
             }});
+        }
         ColParams c1{work, work, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, ncols, 0, tw, p->tw16k, 0, N, 0};
         // (very short column transforms, Q < 64, leave the persistent kernel no butterflies to hide its memory
         //  traffic behind -- and its inverse form spills there: one-tile workgroups are as fast or faster)
@@ -1431,6 +1489,8 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
             hipMemcpy(p->tw_hi, hi.data(), sizeof(double2) * nhi, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(PBH_ERR_HIP, "hipMemcpy(twiddle tables) failed"));
         if ((rc = dev_alloc(p, (void**)&p->work, sizeof(cf) * (size_t)p->S * nsample)) != PBH_OK) return bail(rc);
+    } else if (single_planar_ok(p)) {
+        if ((rc = dev_alloc(p, (void**)&p->work, sizeof(cf) * (size_t)p->S * nsample)) != PBH_OK) return bail(rc);
     }
     if (p->bsL) {
         if ((rc = plain_fft ? setup_bluestein(p) : setup_circular(p)) != PBH_OK) return bail(rc);
@@ -1445,7 +1505,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->sub) pbh_plan_destroy(p->sub);
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) hipFree(p->cf_in);
-    void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->stage_in, p->stage_out,
+    void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -1483,7 +1543,7 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->n2 = p->N2;
     info->variant = resolved_variant(p);
     // (long blocks: +2 for the stand-alone radix-P stage unless it is folded into the layout passes)
-    info->nkernel = p->N1 == 1 ? 1 : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) +
+    info->nkernel = p->N1 == 1 ? ((p->work && single_planar_ok(p)) ? 3 : 1) : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) +
                                          ((p->P > 1 && !radix_layout_ok(p->S, p->P, p->N, p->N2)) ? 2 : 0);
     if (p->bsL && p->cfilt) {
         pbh_plan_info_t sub;
@@ -1696,6 +1756,72 @@ int pbh_pol_basis(int device, void* hip_stream, int /*dtype*/, const void* in_de
 
 #ifndef PBH_F64
 // incoherent dedispersion gather on device data of any dtype: `unit` 4-byte words per (sample, channel)
+// Stream-ordered scratch memory (hipMallocAsync / hipFreeAsync) comes from the device's default pool; by default the pool
+// hands freed memory back to the system at the next synchronisation, which turns a 2-GiB scratch buffer per call into
+// 20 ms of page-table work.  The pool keeps what it has been given until pbh_trim.
+static void keep_pool_memory(int device) {
+    static thread_local bool done[16] = {};
+    if (device < 0 || device >= 16 || done[device]) return;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t keep = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done[device] = true;
+}
+
+// Sample-major arrays of 8-byte elements with a power-of-two number of series: the gather as two full-line passes
+// through a series-major scratch copy (the pipeline's de-interleave kernel, then its re-interleave kernel reading
+// every series at its own time offset) -- 2x the useful bytes, where the direct gather touches a whole 128-byte line
+// for every 16-byte cell (~nchan x).  Returns 1 when the geometry does not fit (the caller gathers directly).
+static int incoherent_two_pass(hipStream_t st, const void* in_dev, void* out_dev, int64_t nout, int nchan, int unit_words,
+                               const int64_t* delay) {
+    static const bool on = [] { const char* e = getenv("PBH_INCOHERENT_2PASS"); return e ? atoi(e) != 0 : true; }();
+    if (!on || unit_words % 2 != 0) return 1;
+    const int per = unit_words / 2;                  // 8-byte elements per (sample, channel) cell
+    const int64_t S64 = (int64_t)nchan * per;
+    if (S64 < 2 || S64 > 128 || (S64 & (S64 - 1)) != 0 || nout < (1 << 16)) return 1;
+    if (((uintptr_t)in_dev | (uintptr_t)out_dev) % 16 != 0) return 1;
+    const int S = (int)S64;
+    int64_t dmax = 0;
+    std::vector<int64_t> dser((size_t)S);
+    for (int s2 = 0; s2 < S; ++s2) {
+        dser[s2] = delay[s2 / per];
+        if (dser[s2] < 0) return 1;
+        if (dser[s2] > dmax) dmax = dser[s2];
+    }
+    const int64_t nin = nout + dmax;                 // input rows the gather can touch
+    const int TN = tr_rows(S);
+    const int64_t plane = (nin + TN - 1) / TN * TN + 16;
+    cf* tmp = nullptr;
+    int64_t* dd = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) keep_pool_memory(dev);
+    if (hipMallocAsync((void**)&tmp, sizeof(cf) * (size_t)plane * S, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;                                    // no room for the scratch copy: gather directly
+    }
+    hipError_t e = hipMallocAsync((void**)&dd, sizeof(int64_t) * (size_t)S, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, dser.data(), sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // dser is a local: staged before it goes out of scope
+    int rc = e == hipSuccess ? PBH_OK : fail(PBH_ERR_HIP, std::string("pbh_incoherent: ") + hipGetErrorString(e));
+    if (rc == PBH_OK) {
+        // whole tiles of the row transposes, the last one zero-padded beyond nin (the scratch planes are long enough)
+        const unsigned grid = (unsigned)((nin + TN - 1) / TN);
+        switch (S) {
+#define X(s2) case s2: hipLaunchKernelGGL(k_deinterleave_p2<s2>, dim3(grid), dim3(256), 0, st, (const cf*)in_dev, tmp, nin, plane, nin); break;
+            X(2) X(4) X(8) X(16) X(32) X(64) X(128)
+#undef X
+        }
+        if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "pbh_incoherent: de-interleave launch failed");
+    }
+    if (rc == PBH_OK) rc = launch_reinterleave(tmp, (cf*)out_dev, 0, nout, S, plane, st, 0, dd);
+    hipFreeAsync(tmp, st);
+    if (dd) hipFreeAsync(dd, st);
+    return rc;
+}
+
 int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nout, int nchan,
                    int unit_words, const int64_t* delay /*[nchan] host, >= 0*/) {
     if (!in_dev || !out_dev || !delay) return fail(PBH_ERR_INVALID, "NULL argument");
@@ -1703,6 +1829,10 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
     if (nout == 0) return PBH_OK;
     HIPCHECK(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
+    {
+        const int rc2 = incoherent_two_pass(st, in_dev, out_dev, nout, nchan, unit_words, delay);
+        if (rc2 <= 0) return rc2;
+    }
     // device copy of the delays: allocated and freed in stream order (no device-wide synchronisation, nothing cached
     // per thread); the host array is staged by the copy before it returns
     int64_t* d = nullptr;
@@ -1725,6 +1855,40 @@ int pbh_incoherent(int device, void* hip_stream, const void* in_dev, void* out_d
     const hipError_t ef = hipFreeAsync(d, st);
     if (e == hipSuccess) e = ef;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_incoherent: ") + hipGetErrorString(e));
+    return PBH_OK;
+}
+
+// The same gather on series-major arrays (time fastest; pitches in 4-byte words between consecutive series): every
+// series is one contiguous run, so it is a shifted copy per series.  unit_words = 4-byte words per element of a series.
+int pbh_incoherent_series(int device, void* hip_stream, const void* in_dev, int64_t in_pitch_words, void* out_dev,
+                          int64_t out_pitch_words, int64_t nout, int nchan, int series_per_chan, int unit_words,
+                          const int64_t* delay /*[nchan] host, >= 0*/) {
+    if (!in_dev || !out_dev || !delay) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nout < 0 || nchan <= 0 || series_per_chan <= 0 || (unit_words != 1 && unit_words != 2 && unit_words != 4))
+        return fail(PBH_ERR_INVALID, "bad size");
+    if (in_pitch_words % unit_words || out_pitch_words % unit_words) return fail(PBH_ERR_INVALID, "pitch is not a whole number of elements");
+    if (nout == 0) return PBH_OK;
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int64_t* d = nullptr;
+    HIPCHECK(hipMallocAsync((void**)&d, sizeof(int64_t) * (size_t)nchan, st));
+    hipError_t e = xfer_h2d(d, delay, sizeof(int64_t) * (size_t)nchan, st);
+    if (e == hipSuccess) {
+        const int64_t ip = in_pitch_words / unit_words, op = out_pitch_words / unit_words;
+        int64_t bx = (nout + 255) / 256;
+        if (bx > 4096) bx = 4096;
+        const dim3 grid((unsigned)bx, (unsigned)(nchan * series_per_chan));
+        if (unit_words == 4)
+            hipLaunchKernelGGL((k_shift_rows<uint4>), grid, dim3(256), 0, st, (const uint4*)in_dev, ip, (uint4*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
+        else if (unit_words == 2)
+            hipLaunchKernelGGL((k_shift_rows<uint2>), grid, dim3(256), 0, st, (const uint2*)in_dev, ip, (uint2*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
+        else
+            hipLaunchKernelGGL((k_shift_rows<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)in_dev, ip, (uint32_t*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
+        e = hipGetLastError();
+    }
+    const hipError_t ef = hipFreeAsync(d, st);
+    if (e == hipSuccess) e = ef;
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_incoherent_series: ") + hipGetErrorString(e));
     return PBH_OK;
 }
 #endif
@@ -1828,6 +1992,79 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     return PBH_OK;
 }
 
+// contrib.stft followed by coherent_dedispersion in one call (pulsarbat/contrib/misc.py:41-55, then
+// transforms/dedispersion.py:125): `plan` is the dedispersion plan of the CHANNELISED block, (nseg, nchan_in*nperseg,
+// inner); the input is the (nseg*nperseg, nchan_in, inner) block the channeliser would read.  Where the geometry
+// allows (float32, nperseg = 2^m in [32, 1024], a multi-pass plan) the channeliser writes its output series-major
+// straight into the plan's work buffer and the dedispersion starts at its column pass -- the channelised block is
+// never written in the reference layout nor de-interleaved again.  Every other geometry runs the two steps one after
+// the other through a scratch copy of the channelised block.
+int PBH_FN(stft)(int device, void* hip_stream, int dtype, const void* in, void* out, int64_t nseg, int nperseg, int nchan,
+                 int inner, int inverse, int in_loc, int out_loc);
+int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nchan_in, void* out_dev, int out_layout,
+                            int64_t out_pitch) {
+    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    if (nperseg <= 0 || nchan_in <= 0 || (int64_t)nchan_in * nperseg != p->nchan)
+        return fail(PBH_ERR_INVALID, "pbh_stft_dedisperse: the plan must have nchan = nchan_in * nperseg channels");
+    if (out_layout != PBH_LAYOUT_SAMPLE_MAJOR && out_layout != PBH_LAYOUT_SERIES_MAJOR) return fail(PBH_ERR_INVALID, "bad layout");
+    const int64_t nout = p->stop - p->start, nseg = p->N;
+    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && out_pitch < nout) return fail(PBH_ERR_INVALID, "out_pitch < output length");
+    HIPCHECK(hipSetDevice(p->device));
+    if (nout <= 0) return PBH_OK;
+    const int E = p->npol, M = nperseg;
+    const int64_t Sin = (int64_t)nchan_in * E;
+    const bool multipass = !(p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+                             p->N >= (1LL << 31));
+    if (out_layout == PBH_LAYOUT_SERIES_MAJOR && !multipass)
+        return fail(PBH_ERR_UNSUPPORTED, "series-major output needs a multi-pass power-of-two plan (nsample > one tile)");
+#ifndef PBH_F64
+    static const bool fuse_on = [] { const char* e = getenv("PBH_STFT_FUSE"); return e ? atoi(e) != 0 : true; }();
+    if (fuse_on && multipass && is_pow2(M) && M >= PBH_R && M * 16 <= kTilePoints) {
+        const int F = kTilePoints / M;
+        int SB = F / 16;
+        while (SB > 1 && (Sin % SB != 0 || SB > Sin)) SB >>= 1;
+        const int G = F / SB;
+        // (a tile that takes fewer than 8 of many series reads 32-byte or smaller pieces of the input's lines: slower
+        //  than the two steps it would replace -- nperseg 256: 5.6 vs 5.2 ms, 512: 6.6 vs 5.0 for 2^24 x 8 x 2)
+        if (nseg % G == 0 && Sin / SB <= 16383 && (SB >= 8 || SB == Sin)) {
+            StftPlanarParams sp{(const cf*)in_dev, p->work, p->tw16k, p->N, (int)Sin, E, SB, G, (real)(1.0 / (double)M)};
+            const int64_t ngrp = nseg / G;
+            int rc = PBH_OK;
+            for (int64_t y0 = 0; y0 < ngrp && rc == PBH_OK; y0 += 65535) {
+                const int64_t cnt = ngrp - y0 < 65535 ? ngrp - y0 : 65535;
+                StftPlanarParams q = sp;
+                q.in = sp.in + y0 * G * (int64_t)M * Sin;
+                q.out = sp.out + y0 * G;
+                switch (M) {
+#define X(m) case m: rc = launch_tile_kernel(k_stft_planar<m, PBH_R>, q, Sin / SB, kTilePoints / PBH_R, p->stream, lds_tile_bytes<false>(), (unsigned)cnt); break;
+                    X(32) X(64) X(128) X(256) X(512) X(1024)
+#undef X
+                    default: rc = fail(PBH_ERR_STATE, "k_stft_planar: unexpected segment length");
+                }
+            }
+            PBHCHECK(rc);
+            IoLayout io;
+            io.in_layout = PBH_LAYOUT_SERIES_MAJOR;
+            io.in_pitch = p->N;
+            io.out_layout = out_layout;
+            io.out_pitch = out_pitch;
+            auto steps = build_steps(p, (const cf*)p->work, (cf*)out_dev, DetectTail(), io);
+            return run_steps(steps, p->stream);
+        }
+    }
+#endif
+    // unfused: channelise into the plan's staging buffer, then the ordinary pipeline
+    const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
+    PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, bytes));
+    PBHCHECK(PBH_FN(stft)(p->device, p->stream, 0, in_dev, p->stage_in, nseg, M, nchan_in, E, 0, PBH_DEVICE, PBH_DEVICE));
+    IoLayout io;
+    io.out_layout = out_layout;
+    io.out_pitch = out_pitch;
+    auto steps = build_steps(p, (const cf*)p->stage_in, (cf*)out_dev, DetectTail(), io);
+    return run_steps(steps, p->stream);
+}
+
 static int launch_place(hipStream_t st, const cf* src, int64_t ipitch, cf* dst, int64_t opitch, int64_t nrow, int ncol) {
     // 16-byte vectors when every row of both sides starts and ends on one
     const bool v16 = sizeof(cf) == 16 || (ncol % 2 == 0 && ipitch % 2 == 0 && opitch % 2 == 0 &&
@@ -1887,6 +2124,35 @@ int pbh_place(int device, void* hip_stream, int /*dtype: this build's*/, const v
     if (nrow == 0 || ncol == 0) return PBH_OK;
     HIPCHECK(hipSetDevice(device));
     return launch_place((hipStream_t)hip_stream, (const cf*)src_dev, src_row_elems, (cf*)dst_dev, dst_row_elems, nrow, (int)ncol);
+}
+
+// freq_shift (pulsarbat/transforms/transforms.py:337-361): out = IFFT(H * FFT(x * exp(2 pi i ft n))) with the plan's H (the
+// band mask of pbh_chirp_special mode 1).  The mixer rides in the de-interleave pass where the plan has one that can
+// carry it; otherwise it is ONE out-of-place pass into the plan's staging buffer (no separate copy of the caller's data).
+int pbh_dedisperse_mix(pbh_plan* p, const void* in_dev, void* out_dev, const double* ft /*[nchan*npol] host, cycles per sample*/) {
+    if (!p || !in_dev || !out_dev || !ft) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no filter: call pbh_chirp_special / pbh_chirp_upload first");
+    HIPCHECK(hipSetDevice(p->device));
+    if (p->stop <= p->start) return PBH_OK;
+    if (!p->mix_ft) PBHCHECK(dev_alloc(p, (void**)&p->mix_ft, sizeof(double) * (size_t)p->S));
+    HIPCHECK(hipMemcpyAsync(p->mix_ft, ft, sizeof(double) * (size_t)p->S, hipMemcpyHostToDevice, p->stream));
+    HIPCHECK(hipStreamSynchronize(p->stream));   // ft is a borrowed host array
+    const bool fold = !p->bsL && p->N1 > 1 && p->P == 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && deint_can_mix(p->S, p->N);
+    if (fold) {
+        IoLayout io;
+        io.mix_ft = p->mix_ft;
+        auto steps = build_steps(p, (const cf*)in_dev, (cf*)out_dev, DetectTail(), io);
+        return run_steps(steps, p->stream);
+    }
+    const size_t in_bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
+    PBHCHECK(ensure_stage(p, &p->stage_in, &p->stage_in_bytes, in_bytes));
+    int64_t blocks = (p->N * p->S + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_mix, dim3((unsigned)blocks), dim3(256), 0, p->stream, (const cf*)in_dev, (cf*)p->stage_in,
+                       (const double*)p->mix_ft, p->N, p->S);
+    HIPCHECK(hipGetLastError());
+    auto steps = build_steps(p, (const cf*)p->stage_in, (cf*)out_dev);
+    return run_steps(steps, p->stream);
 }
 
 static int detect_out_elems(int mode, int npol) {
@@ -2077,6 +2343,11 @@ int pbh_trim(void) {
             }
             g_tw_table[d] = nullptr;
         }
+    for (int d = 0; d < 16; ++d) {   // stream-ordered scratch memory kept by the default pools (keep_pool_memory)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+        (void)hipGetLastError();
+    }
     if (have_cur) hipSetDevice(cur);
     release_bounce_buffers();
     return PBH_OK;

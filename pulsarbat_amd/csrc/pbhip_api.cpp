@@ -35,6 +35,7 @@
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
     int P##dedisperse_slice(P##plan*, const void*, void*, int64_t, int64_t);                                    \
+    int P##dedisperse_mix(P##plan*, const void*, void*, const double*);                                         \
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
@@ -43,6 +44,7 @@
     int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
     int P##fft_c2c(int, void*, int, const void*, void*, int64_t, int64_t, int, int, int);                       \
     int P##stft(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                    \
+    int P##stft_dedisperse(P##plan*, const void*, int, int, void*, int, int64_t);                               \
     int P##plan_profile(P##plan*, const void*, void*, int, float*, int*, const char**);                         \
     }
 PBH_DECLARE_IMPL(pbh32_)
@@ -53,6 +55,7 @@ const char* pbh32_version(void);
 int pbh32_chirp_function(int, void*, double, int64_t, double, double, double, void*, int);
 int pbh32_copy_bench(int, int64_t, int, float*);
 int pbh32_incoherent(int, void*, const void*, void*, int64_t, int, int, const int64_t*);
+int pbh32_incoherent_series(int, void*, const void*, int64_t, void*, int64_t, int64_t, int, int, int, const int64_t*);
 }
 
 struct pbh_plan {
@@ -149,6 +152,10 @@ int pbh_decimate2(int device, void* stream, int dtype, const void* in, void* out
 int pbh_incoherent(int device, void* stream, const void* in, void* out, int64_t nout, int nchan, int unit, const int64_t* d) {
     return done(PBH_C64, pbh32_incoherent(device, stream, in, out, nout, nchan, unit, d));
 }
+int pbh_incoherent_series(int device, void* stream, const void* in, int64_t ip, void* out, int64_t op, int64_t nout, int nchan,
+                          int spc, int unit, const int64_t* d) {
+    return done(PBH_C64, pbh32_incoherent_series(device, stream, in, ip, out, op, nout, nchan, spc, unit, d));
+}
 int pbh_chirp_function(int device, void* stream, double coeff, int64_t n, double dt, double fc, double fr, void* out, int loc) {
     return done(PBH_C64, pbh32_chirp_function(device, stream, coeff, n, dt, fc, fr, out, loc));
 }
@@ -186,6 +193,9 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in, int il, int64_t ip, void*
 int pbh_dedisperse_slice(pbh_plan* p, const void* in, void* out, int64_t row, int64_t off) {
     FORWARD(p, pbh32_dedisperse_slice(P32(p), in, out, row, off), pbh64_dedisperse_slice(P64(p), in, out, row, off));
 }
+int pbh_dedisperse_mix(pbh_plan* p, const void* in, void* out, const double* ft) {
+    FORWARD(p, pbh32_dedisperse_mix(P32(p), in, out, ft), pbh64_dedisperse_mix(P64(p), in, out, ft));
+}
 int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in, int il, int64_t ip, void* out, int ns, int mode) {
     FORWARD(p, pbh32_dedisperse_detect_layout(P32(p), in, il, ip, out, ns, mode), pbh64_dedisperse_detect_layout(P64(p), in, il, ip, out, ns, mode));
 }
@@ -217,6 +227,9 @@ int pbh_stft(int device, void* stream, int dtype, const void* in, void* out, int
     if (dtype == PBH_C128) return done(PBH_C128, pbh64_stft(device, stream, dtype, in, out, nseg, nperseg, nchan, inner, inverse, il, ol));
     if (dtype == PBH_C64) return done(PBH_C64, pbh32_stft(device, stream, dtype, in, out, nseg, nperseg, nchan, inner, inverse, il, ol));
     return fail_here(PBH_ERR_UNSUPPORTED, "dtype must be PBH_C64 or PBH_C128");
+}
+int pbh_stft_dedisperse(pbh_plan* p, const void* in, int nperseg, int nchan_in, void* out, int ol, int64_t op) {
+    FORWARD(p, pbh32_stft_dedisperse(P32(p), in, nperseg, nchan_in, out, ol, op), pbh64_stft_dedisperse(P64(p), in, nperseg, nchan_in, out, ol, op));
 }
 int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* ms, int* nk, const char** names) {
     FORWARD(p, pbh32_plan_profile(P32(p), in, out, iters, ms, nk, names), pbh64_plan_profile(P64(p), in, out, iters, ms, nk, names));

@@ -372,9 +372,7 @@ def incoherent_dedispersion(z, DM, /, *, ref_freq=None):
     if isinstance(z.data, DeviceArray) and not z.data.tensor.is_contiguous() and z.data.series_major_pitch() is not None:
         # series-major (time fastest): every channel is a contiguous run -- one shifted copy per channel instead of
         # the line-granular gather of the sample-major layout
-        x = DeviceArray.empty_series_major((max(N, 0),) + tuple(z.sample_shape), z.dtype, device=z.data.device_index)
-        for i, j in enumerate(delays):
-            x.tensor[:, i].copy_(z.data.tensor[int(j):int(j) + max(N, 0), i])
+        x = _hip.incoherent_series(z.data, delays, max(N, 0))
     elif isinstance(z.data, DeviceArray):
         x = _hip.incoherent(z.data, delays, max(N, 0))
     else:

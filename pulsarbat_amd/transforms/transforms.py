@@ -112,12 +112,11 @@ def freq_shift(z, /, shift):
     N = len(z)
     x, on_dev, real, dt = _to_device_complex(z)
     S = ft.size
-    xm = DeviceArray(x.tensor.reshape(N, S).clone())  # the mixer works in place: keep the caller's data
-    _hip.mix(xm, ft)
     same = bool(np.all(ft == ft[0]))   # one shift for every series: a single shared band mask
-    plan = _hip.filter_plan(N, S, 0, N, xm.device_index, xm.dtype, shared=same)
+    plan = _hip.filter_plan(N, S, 0, N, x.device_index, x.dtype, shared=same)
     plan.chirp_special((ft[:1] if same else ft) * N, 1)
-    y = plan.dedisperse(DeviceArray(xm.tensor.reshape((N, 1, S) if same else (N, S, 1))))
+    # the mixer exp(2 pi i ft n) is applied inside the transform's first pass (no copy, no mixing pass of its own)
+    y = plan.dedisperse_mix(DeviceArray(x.tensor.reshape((N, 1, S) if same else (N, S, 1))), ft)
     out = _from_device(DeviceArray(y.tensor.reshape(N, S)), on_dev, False, dt, (N,) + tuple(z.sample_shape))
     return type(z).like(z, out)
 

@@ -130,3 +130,41 @@ class TestSTFT:
         assert np.linalg.norm(np.asarray(s) - want) / np.linalg.norm(want) < tol
         y = pb.contrib.istft(s, nperseg=n)
         assert np.linalg.norm(np.asarray(y) - x[: len(y)]) / np.linalg.norm(x[: len(y)]) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,nperseg,dm", [
+    ((1 << 21, 8, 2), 64, 30.0),     # 16 series per tile: whole input lines, 128-byte series-major runs
+    ((1 << 23, 2, 2), 256, 60.0),    # 4 input series: the tile takes all of them
+    ((1 << 22, 8, 2), 128, 80.0),    # 8 of the 16 series per tile (sibling tiles share the input's lines)
+    ((1 << 21, 8, 2), 512, 40.0),    # 2 of 16 series per tile would be slower than two steps: two steps in the one call
+    ((1 << 20, 3, 2), 32, 20.0),     # 6 input series: a subset size that divides them
+    ((1 << 22, 2), 128, 10.0),       # single-pol baseband signal
+    ((1 << 18, 4, 2), 2048, 5.0),    # beyond the fused kernel's segment lengths: two steps
+    ((1 << 16, 2, 2), 64, 1.0),      # channelised block of one tile: two steps
+])
+def test_stft_dedisperse_fused(shape, nperseg, dm):
+    """contrib.stft followed by coherent_dedispersion as one library call (pbh_stft_dedisperse) against the oracle's
+    composition of the two reference functions (misc.py:41-55, dedispersion.py:118-133), and against the product's own
+    two-call form: values, crop, start_time, sample rate and channel grid."""
+    sr, fc = 8e6, 1.3e9
+    x = orc.synthetic_block(shape, 17)
+    kw = dict(sample_rate=sr * u.Hz, center_freq=fc * u.Hz, start_time=pb.Time(56000.0, format="mjd"))
+    z = (pb.DualPolarizationSignal(x, pol_type="linear", **kw) if len(shape) == 3 else pb.BasebandSignal(x, **kw))
+    zd = z.to_device()
+    y = pb.contrib.stft_dedisperse(zd, pb.DM(dm), nperseg=nperseg)
+    ch = orc.stft(x, nperseg)
+    want, start, stop = orc.coherent_dedispersion(ch, dm, sr / nperseg, fc, freq_align="bottom")
+    assert want.shape[0] > 0
+    assert isinstance(y.data, pb.DeviceArray) and type(y) is type(z) and y.shape == want.shape
+    got = np.asarray(y).reshape(want.shape[0], -1)
+    ref = want.reshape(want.shape[0], -1)
+    err = np.linalg.norm(got - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    assert err.max() < 1e-5, f"per-series relative L2 {err.max():.2e}"
+    two = pb.coherent_dedispersion(pb.contrib.stft(zd, nperseg=nperseg), pb.DM(dm))
+    assert_equal_radiosignals(y, two)
+    assert abs((y.start_time - z.start_time).to_value(u.s) - start * nperseg / sr) < 1e-12
+    # host signals take the two-step route and agree
+    if shape[0] <= 1 << 20:
+        yh = pb.contrib.stft_dedisperse(z, pb.DM(dm), nperseg=nperseg)
+        assert isinstance(yh.data, np.ndarray) and np.allclose(np.asarray(yh), np.asarray(y), atol=2e-6)

@@ -233,8 +233,49 @@ def test_fft_dispatch_device():
         want = getattr(scipy.fft, name)(x, axis=0)
         assert type(got) is type(d) and got.dtype == want.dtype
         assert np.linalg.norm(np.asarray(got) - want) / np.linalg.norm(want) < 1e-6
-    with pytest.raises(NotImplementedError):
-        pb.fft.rfft(d)
+    with pytest.raises(TypeError):
+        pb.fft.rfft(d)   # scipy: "x must be a real sequence"
+
+
+def test_fft_all_names_axes_n_norm_on_device():
+    """The reference's pb.fft exposes fourteen scipy.fft names and dispatches each on the array type (fft.py:8-48; its
+    channeliser calls pb.fft.fft(x, axis=2, n=nfft), contrib/misc.py:47): every name on a DeviceArray must return a
+    DeviceArray equal to scipy's result for scipy's n / s / axis / axes / norm arguments."""
+    import scipy.fft
+    rng = np.random.default_rng(3)
+    xc = (rng.standard_normal((6, 40, 48)) + 1j * rng.standard_normal((6, 40, 48))).astype(np.complex64)
+    xr = rng.standard_normal((6, 40, 48)).astype(np.float32)
+    dc, dr = pb.DeviceArray.from_host(xc), pb.DeviceArray.from_host(xr)
+
+    def same(name, dev, host, tol=2e-6, **kw):
+        got = getattr(pb.fft, name)(dev, **kw)
+        want = getattr(scipy.fft, name)(host, **kw)
+        assert isinstance(got, pb.DeviceArray), name
+        g = np.asarray(got)
+        assert g.shape == want.shape and g.dtype == want.dtype, (name, kw, g.shape, want.shape, g.dtype, want.dtype)
+        assert np.linalg.norm(g - want) / np.linalg.norm(want) < tol, (name, kw)
+
+    for name in ("fft", "ifft"):
+        same(name, dc, xc)                                  # last axis by default
+        same(name, dc, xc, axis=2, n=64)                    # the channeliser's call: zero padding
+        same(name, dc, xc, axis=1, n=33)                    # truncation to an odd length
+        same(name, dc, xc, axis=0, norm="ortho")
+        same(name, dc, xc, axis=-2, norm="forward")
+    for name in ("fft2", "ifft2", "fftn", "ifftn"):
+        same(name, dc, xc)
+        same(name, dc, xc, s=(32, 50), axes=(1, 2), norm="ortho")
+    same("rfft", dr, xr)
+    same("rfft", dr, xr, n=50, axis=1)
+    same("rfft2", dr, xr)
+    same("rfftn", dr, xr, s=(8, 40, 30))
+    same("ihfft", dr, xr, axis=1)
+    for n in (None, 94, 95, 60):
+        same("irfft", dc, xc, n=n)
+        same("hfft", dc, xc, n=n, tol=4e-6)
+    same("irfft2", dc, xc)
+    same("irfftn", dc, xc, s=(6, 40, 77))
+    with pytest.raises(ValueError):
+        pb.fft.fft(dc, norm="bogus")
 
 
 @pytest.mark.parametrize("shape,dm", [((1000, 2), 1.0), ((16, 3), 0.001), ((6, 1), 0.0), ((8190, 4, 2), 10.0),
@@ -886,3 +927,41 @@ def test_layout_conversion(shape, dtype):
         s2 = pb.DeviceArray.empty_series_major(shape, dtype, align_start=3)
         _hip.relayout(s, s2)            # series-major -> series-major with another pitch / offset
         assert np.array_equal(np.asarray(s2), x)
+
+
+@pytest.mark.parametrize("shape,dm,dtype", [((1 << 14, 256, 2), 20.0, np.complex64), ((4096, 1024, 2), 5.0, np.complex64),
+                                            ((8192, 600), 10.0, np.complex64), ((2048, 512, 4), 2.0, np.complex64),
+                                            ((4096, 256, 2), 5.0, np.complex128), ((1 << 14, 96, 1), 20.0, np.complex64)])
+def test_one_tile_blocks_with_many_series(shape, dm, dtype):
+    """Channelised blocks no longer than a tile (what stft with long segments hands to coherent_dedispersion): layout
+    pass + planar row pass + layout pass; rows of a tile share chirp rows polarisation by polarisation."""
+    sr, fc = 1e6 / 64, 1e9
+    x = orc.synthetic_block(shape, 23).astype(dtype)
+    z = make_signal(x, sr, fc, start_time=pb.Time(56000.0, format="mjd"))
+    for zz in (z, z.to_device()):
+        y = pb.coherent_dedispersion(zz, pb.DM(dm))
+        yr, start, stop = orc.coherent_dedispersion(x, dm, sr, fc)
+        assert y.shape == yr.shape and yr.shape[0] > 0 and y.dtype == dtype
+        l2, mx = series_errors(y, yr)
+        assert l2 < (RTOL_L2 if dtype == np.complex64 else 1e-8), f"relative L2 {l2:.2e}"   # (complex128: the chirp is complex64-rounded on both sides; last-bit flips of that rounding)
+
+
+def test_channelised_block_beyond_2gib():
+    """2^14 samples x 8192 channels x 2 pol (2 GiB): the shape contrib.stft(nperseg=1024) makes of the headline block."""
+    import torch
+    n, nchan, npol, sr, fc, dm = 1 << 14, 8192, 2, 50e6 / 1024, 1.4e9, 56.77
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xt = torch.view_as_complex(torch.randn((n, nchan, npol, 2), generator=g, device="cuda", dtype=torch.float32))
+    z = pb.DualPolarizationSignal(pb.DeviceArray(xt), sample_rate=sr * u.Hz, center_freq=fc * u.Hz, pol_type="linear",
+                                  freq_align="bottom")
+    y = pb.coherent_dedispersion(z, pb.DM(dm))
+    start, stop = orc.crop_bounds(dm, n, nchan, sr, fc, fc)
+    assert y.shape == (stop - start, nchan, npol)
+    import scipy.fft
+    freqs = orc.channel_freqs(fc, sr, nchan, "bottom")
+    for c in (0, 1, 4095, 8191):
+        chirp = orc.transfer_function(dm, n, 1 / sr, freqs[c], fc)[:, None]
+        xs = xt[:, c, :].cpu().numpy()
+        ref = scipy.fft.ifft(scipy.fft.fft(xs, axis=0) * chirp, axis=0)[start:stop]
+        got = y.data.tensor[:, c, :].cpu().numpy()
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < RTOL_L2
