@@ -1033,12 +1033,18 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
     if (L->blk_samples <= 0 || L->blk_stride < 0 || L->hdr_bytes < 0) return fail(PBH_ERR_INVALID, "bad block geometry");
     if ((int64_t)nchan * npol > 65535LL * 64) return fail(PBH_ERR_UNSUPPORTED, "too many series");
     const int64_t b0 = first / L->blk_samples, b1 = (first + nsample - 1) / L->blk_samples;
+    // every product of caller-supplied strides, counts and sizes below is checked: a layout whose addressing does not fit
+    // 63 bits is rejected, not wrapped (the bounds checks that follow are only as good as the arithmetic under them)
+    bool ovf = false;
+    auto mul = [&](int64_t a, int64_t b) { int64_t r = 0; ovf |= __builtin_mul_overflow(a, b, &r); return r; };
+    auto add = [&](int64_t a, int64_t b) { int64_t r = 0; ovf |= __builtin_add_overflow(a, b, &r); return r; };
+    if (first > INT64_MAX - nsample) return fail(PBH_ERR_INVALID, "sample range overflows");
     // [lo, hi]: element indices reached over time samples [ta, tb] of one payload
     auto reach = [&](int64_t ta, int64_t tb, int64_t* lo, int64_t* hi) {
         *lo = *hi = L->elem0;
         auto span = [&](int64_t stride, int64_t a, int64_t b) {
-            *lo += stride >= 0 ? stride * a : stride * b;
-            *hi += stride >= 0 ? stride * b : stride * a;
+            *lo = add(*lo, stride >= 0 ? mul(stride, a) : mul(stride, b));
+            *hi = add(*hi, stride >= 0 ? mul(stride, b) : mul(stride, a));
         };
         span(L->stride_t, ta, tb);
         span(L->stride_c, 0, nchan - 1);
@@ -1048,6 +1054,7 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
     const int64_t t_first = first - b0 * L->blk_samples, t_last = first + nsample - 1 - b1 * L->blk_samples;
     int64_t lo, hi, lo2, hi2;
     reach(b1 > b0 ? 0 : t_first, t_last, &lo, &hi);   // the last block: what bounds the buffer
+    if (ovf || hi < 0 || hi > (INT64_MAX - 8) / bits - 1) return fail(PBH_ERR_INVALID, "payload addressing overflows");
     const int64_t pay_hi = ((hi + 1) * bits + 7) / 8;
     if (b1 > b0) {                                      // earlier blocks are read up to their last sample
         reach(b1 > b0 + 1 ? 0 : t_first, L->blk_samples - 1, &lo2, &hi2);
@@ -1056,12 +1063,15 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
             reach(t_first, L->blk_samples - 1, &lo3, &hi3);
             lo2 = lo3 < lo2 ? lo3 : lo2;
         }
-        if (L->hdr_bytes + ((hi2 + 1) * bits + 7) / 8 > L->blk_stride)
+        if (ovf || hi2 < 0 || hi2 > (INT64_MAX - 8) / bits - 1) return fail(PBH_ERR_INVALID, "payload addressing overflows");
+        if (add(L->hdr_bytes, ((hi2 + 1) * bits + 7) / 8) > L->blk_stride || ovf)
             return fail(PBH_ERR_INVALID, "payload addressing overruns a block");
         lo = lo2 < lo ? lo2 : lo;
     }
     if (lo < 0) return fail(PBH_ERR_INVALID, "payload addressing reaches before the payload");
-    if ((uint64_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) > (uint64_t)raw_bytes)
+    const int64_t end_byte = add(add(mul(b1, L->blk_stride), L->hdr_bytes), pay_hi);
+    if (ovf) return fail(PBH_ERR_INVALID, "payload addressing overflows");
+    if ((uint64_t)end_byte > (uint64_t)raw_bytes)
         return fail(PBH_ERR_INVALID, "raw buffer too short for the requested samples");
     sp->b0 = b0;
     sp->b1 = b1;
@@ -1071,7 +1081,7 @@ static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample
     reach(t_first, b1 > b0 ? L->blk_samples - 1 : t_last, &lo_first, &hi_first);
     const int64_t skip = (L->hdr_bytes + lo_first * bits / 8) & ~(int64_t)15;
     sp->off = (size_t)(b0 * L->blk_stride + skip);
-    sp->len = (size_t)(b1 * L->blk_stride + L->hdr_bytes + pay_hi) - sp->off;
+    sp->len = (size_t)end_byte - sp->off;
     return PBH_OK;
 }
 

@@ -1,7 +1,9 @@
-"""Reader base class (reference pulsarbat/readers/_base.py:38-360): sample bookkeeping (offset <-> time),
-bounds checks, and ``read(offset, n)`` wrapping whatever ``_read_array`` returns in the reader's signal type.
-The dask branch of the reference (``use_dask=True`` / ``dask_read``) has no counterpart: reads return numpy or
-device arrays, and the keyword is accepted and ignored so that reference call sites keep working."""
+"""Reader base class: the public contract of the reference's ``pulsarbat.readers.BaseReader``
+(pulsarbat/readers/_base.py:44-105 states it: a stream of ``shape[0]`` samples of ``shape[1:]`` / ``dtype`` at
+``sample_rate`` starting at ``start_time``; ``read(offset, n)`` returns a ``signal_type``), written around two small
+pieces of this build's own: a sample clock (offset <-> time arithmetic) and a stream description.  There is no dask
+branch: reads return numpy or device arrays, and the reference's ``use_dask`` / ``chunks`` keywords are accepted and
+ignored so that call sites written for the reference keep working."""
 
 import operator
 
@@ -15,139 +17,187 @@ __all__ = ["BaseReader", "OutOfBoundsError"]
 
 
 class OutOfBoundsError(EOFError):
-    """A position outside the stream was asked for (_base.py:38-41)."""
+    """A position before the first or after the last sample of the stream was asked for."""
+
+
+class _SampleClock:
+    """Sample index <-> time for a uniformly sampled stream: ``rate`` samples per second from ``epoch`` (a Time, or
+    None for a stream without absolute times), ``count`` samples long."""
+
+    def __init__(self, rate, epoch, count):
+        self.rate, self.epoch, self.count = rate, epoch, count
+
+    def elapsed(self, index, unit=u.s):
+        return (index / self.rate).to(unit)
+
+    def instant(self, index):
+        return None if self.epoch is None else self.epoch + index / self.rate
+
+    def index_of(self, when):
+        """Nearest sample index of an absolute Time or of a duration since the first sample."""
+        since = when - self.epoch if isinstance(when, Time) else when
+        k = int(round(float(u.to_value(since * self.rate, u.one))))
+        if not 0 <= k <= self.count:
+            raise OutOfBoundsError("Given time is out of bounds!")
+        return k
+
+    def covers(self, when):
+        """True inside [first sample, end of stream); the end is excluded even when rounding lands exactly on it."""
+        if self.epoch is None:
+            return False
+        first, end = self.epoch, self.instant(self.count)
+        if when.isclose(end) and not when.isclose(first):
+            return False
+        return bool(first <= when < end)
 
 
 class BaseReader:
-    """``shape`` / ``dtype`` / ``sample_rate`` / ``start_time`` of a stream of samples and ``read(offset, n)``
-    (_base.py:44-105).  Subclasses supply ``_read_array(offset, n)``; extra keyword arguments become both
-    attributes of the reader and arguments of ``signal_type``."""
+    """A stream of samples that can be read in pieces.
+
+    Subclasses implement ``_read_array(offset, n, /)`` (or override ``read``).  Constructor arguments as in the
+    reference: ``shape`` (whole stream), ``dtype``, ``signal_type`` (a Signal subclass, default Signal),
+    ``sample_rate`` (frequency Quantity), ``start_time`` (Time or None); any further keyword is kept both as an
+    attribute of the reader and as an argument for ``signal_type``."""
 
     def __init__(self, /, *, shape, dtype, signal_type=Signal, sample_rate, start_time=None, **signal_kwargs):
-        if not (isinstance(signal_type, type) and issubclass(signal_type, Signal)):
+        if not isinstance(signal_type, type) or not issubclass(signal_type, Signal):
             raise ValueError("Bad signal_type. Must be Signal or subclass.")
-        self._signal_type = signal_type
-        self._signal_kwargs = signal_kwargs
-        for name, value in signal_kwargs.items():
-            setattr(self, name, value)
-        self._dtype = np.dtype(dtype)
-        self._shape = tuple(operator.index(a) for a in shape)
-        if not self._shape:
+        dims = tuple(operator.index(d) for d in shape)
+        if len(dims) == 0:
             raise ValueError("Invalid shape.")
+        self._signal_type, self._signal_kwargs = signal_type, dict(signal_kwargs)
+        self.__dict__.update(self._signal_kwargs)           # center_freq, pol_type, ... readable off the reader
+        self._shape, self._dtype = dims, np.dtype(dtype)
         self.sample_rate = sample_rate
         self.start_time = start_time
-        # an empty read now surfaces a reader whose output disagrees with its declared shape / dtype
-        z = self.read(0, 0)
-        if z.shape != (0,) + self.sample_shape:
+        self._self_check()
+
+    def _self_check(self):
+        """A zero-length read exposes a subclass whose output disagrees with what it declared, at construction."""
+        probe = self.read(0, 0)
+        if tuple(probe.shape) != (0,) + self.sample_shape:
             raise ValueError("Provided shape does not match output shape!")
-        if z.dtype != self.dtype:
+        if probe.dtype != self._dtype:
             raise ValueError("Provided dtype does not match output dtype!")
 
-    # ---- description ---------------------------------------------------------------------------------
-    def _attr_repr(self):
-        st = "N/A" if self.start_time is None else self.start_time.isot
-        return f"Start time: {st}\nSample rate: {self.sample_rate}\nTime length: {self.time_length}\n"
+    # ---- what the stream is --------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        """Shape of the whole stream, time first."""
+        return self._shape
 
-    def __str__(self):
-        head = f"{type(self).__name__} @ {hex(id(self))}"
-        body = f"Data Container: {self._signal_type.__name__}<shape={self.shape}, dtype={self.dtype}>\n"
-        return (f"{head}\n{'-' * len(head)}\n{body}{self._attr_repr()}").strip()
+    @property
+    def sample_shape(self):
+        """Shape of one time sample."""
+        return self._shape[1:]
 
-    def __repr__(self):
-        return (f"{type(self).__name__}<{self._signal_type.__name__}(shape={self.shape}, dtype={self.dtype})>"
-                f" @ {hex(id(self))}")
+    @property
+    def ndim(self):
+        return len(self._shape)
 
-    def __dir__(self):
-        return sorted(set(object.__dir__(self)) | set(self._signal_kwargs))
+    @property
+    def dtype(self):
+        return self._dtype
 
     def __len__(self):
         return self._shape[0]
 
-    shape = property(lambda self: self._shape, doc="Shape of the whole stream.")
-    sample_shape = property(lambda self: self._shape[1:], doc="Shape of one sample.")
-    ndim = property(lambda self: len(self._shape))
-    dtype = property(lambda self: self._dtype)
-
-    # ---- time axis -----------------------------------------------------------------------------------
     @property
     def sample_rate(self):
         return self._sample_rate
 
     @sample_rate.setter
-    def sample_rate(self, sample_rate):
-        self._sample_rate = _positive_frequency("sample_rate", sample_rate)
+    def sample_rate(self, value):
+        self._sample_rate = _positive_frequency("sample_rate", value)
 
     @property
     def start_time(self):
         return self._start_time
 
     @start_time.setter
-    def start_time(self, start_time):
+    def start_time(self, value):
+        if value is None:
+            self._start_time = None
+            return
         try:
-            t = None if start_time is None else Time(start_time, format="isot", precision=9)
-            assert t is None or t.isscalar
+            stamp = Time(value, format="isot", precision=9)
+            scalar = stamp.isscalar
         except Exception:
+            scalar = False
+        if not scalar:
             raise ValueError("Invalid start_time. Must be a scalar astropy Time object.")
-        self._start_time = t
+        self._start_time = stamp
+
+    @property
+    def _clock(self):
+        return _SampleClock(self._sample_rate, self._start_time, self._shape[0])
 
     @property
     def stop_time(self):
-        return self.time_at(len(self))
+        """Time just after the last sample (None without a start_time)."""
+        return self._clock.instant(len(self))
 
     @property
     def dt(self):
-        return (1 / self.sample_rate).to(u.s)
+        return self._clock.elapsed(1)
 
     @property
     def time_length(self):
-        return (len(self) / self.sample_rate).to(u.s)
+        return self._clock.elapsed(len(self))
 
-    def contains(self, t, /):
-        """Whether time(s) fall in [start, stop), the stop edge excluded up to rounding (_base.py:210-217)."""
-        many = isinstance(t, (list, tuple, np.ndarray))
-        if self.start_time is None:
-            return np.zeros(len(t), bool) if many else False
-        t0, t1 = self.start_time, self.stop_time
-
-        def one(x):
-            edge = (not x.isclose(t1)) or x.isclose(t0)
-            return bool(edge and t0 <= x < t1)
-        return np.array([one(x) for x in t]) if many else one(t)
-
-    def __contains__(self, t):
-        return self.contains(t)
+    # ---- time <-> offset -----------------------------------------------------------------------------------
+    def time_at(self, offset, /, unit=None):
+        """Time of sample ``offset``: with ``unit`` the duration since the start, otherwise the absolute Time."""
+        return self._clock.instant(offset) if unit is None else self._clock.elapsed(offset, unit)
 
     def offset_at(self, t, /):
-        """Nearest sample offset of an absolute Time or of a time Quantity relative to the start (_base.py:223-247)."""
-        if isinstance(t, Time):
-            t = t - self.start_time
-        offset = int(round(float(u.to_value(t * self.sample_rate, u.one))))
-        if offset < 0 or offset > len(self):
-            raise OutOfBoundsError("Given time is out of bounds!")
-        return offset
+        """Nearest sample offset to ``t`` (a Time, or a time Quantity counted from the start)."""
+        return self._clock.index_of(t)
 
-    def time_at(self, offset, /, unit=None):
-        """Time of a sample offset: a Quantity in ``unit`` from the start, else the absolute Time (_base.py:249-273)."""
-        if unit is not None:
-            return (offset / self.sample_rate).to(unit)
-        if self.start_time is None:
-            return None
-        return self.start_time + (offset / self.sample_rate)
+    def contains(self, t, /):
+        """Whether ``t`` (one Time, or a sequence of them) lies within the stream."""
+        clock = self._clock
+        if isinstance(t, (list, tuple, np.ndarray)):
+            return np.fromiter((clock.covers(x) for x in t), dtype=bool, count=len(t))
+        return clock.covers(t)
 
-    # ---- reading -------------------------------------------------------------------------------------
+    __contains__ = contains
+
+    # ---- reading -------------------------------------------------------------------------------------------
     def _read_array(self, offset, n, /):
         return NotImplemented
 
     def read(self, offset, n, /, **kwargs):
-        """``n`` samples from ``offset`` as a ``signal_type`` whose ``start_time`` is ``time_at(offset)``
-        (_base.py:298-333)."""
-        kwargs.pop("use_dask", None)
-        kwargs.pop("chunks", None)
-        if (offset := operator.index(offset)) < 0:
+        """``n`` samples from sample ``offset``, as a ``signal_type`` that starts at ``time_at(offset)``."""
+        for ignored in ("use_dask", "chunks"):
+            kwargs.pop(ignored, None)
+        first, count = operator.index(offset), operator.index(n)
+        if first < 0:
             raise ValueError("offset must be a non-negative int.")
-        if (n := operator.index(n)) < 0:
+        if count < 0:
             raise ValueError("n must be a non-negative int.")
-        if offset + n > len(self):
+        if first + count > len(self):
             raise OutOfBoundsError("Cannot read beyond end of stream")
-        return self._signal_type(self._read_array(offset, n, **kwargs), sample_rate=self.sample_rate,
-                                 start_time=self.time_at(offset), **self._signal_kwargs)
+        data = self._read_array(first, count, **kwargs)
+        return self._signal_type(data, sample_rate=self._sample_rate, start_time=self.time_at(first),
+                                 **self._signal_kwargs)
+
+    # ---- presentation --------------------------------------------------------------------------------------
+    def _container(self):
+        return f"{self._signal_type.__name__}<shape={self.shape}, dtype={self.dtype}>"
+
+    def _attr_repr(self):
+        began = "N/A" if self._start_time is None else self._start_time.isot
+        return "".join(f"{label}: {value}\n" for label, value in
+                       (("Start time", began), ("Sample rate", self.sample_rate), ("Time length", self.time_length)))
+
+    def __str__(self):
+        title = f"{type(self).__name__} @ {hex(id(self))}"
+        return f"{title}\n{'-' * len(title)}\nData Container: {self._container()}\n{self._attr_repr()}".strip()
+
+    def __repr__(self):
+        kind = self._signal_type.__name__
+        return f"{type(self).__name__}<{kind}(shape={self.shape}, dtype={self.dtype})> @ {hex(id(self))}"
+
+    def __dir__(self):
+        return sorted({*object.__dir__(self), *self._signal_kwargs})

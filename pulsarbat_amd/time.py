@@ -82,12 +82,19 @@ class Time:
 
     @property
     def isot(self):
-        date = _dt.date.fromordinal(self._day - _MJD_UNIX_EPOCH + _dt.date(1970, 1, 1).toordinal())
-        whole = int(self._sec)
-        frac = self._sec - whole
+        # round the seconds of the day to the printed precision FIRST, as an integer count of 10^-precision seconds, so
+        # that 59.9999999996 s carries into the minute (hour, day) instead of printing ":59" + ".000000000"
+        unit = 10 ** self.precision
+        ticks = int(round(self._sec * unit))
+        day = self._day
+        if ticks >= 86400 * unit:
+            ticks -= 86400 * unit
+            day += 1
+        whole, frac = divmod(ticks, unit)
+        date = _dt.date.fromordinal(day - _MJD_UNIX_EPOCH + _dt.date(1970, 1, 1).toordinal())
         h, rem = divmod(whole, 3600)
         mi, s = divmod(rem, 60)
-        fs = f"{frac:.{self.precision}f}"[1:] if self.precision else ""
+        fs = f".{frac:0{self.precision}d}" if self.precision else ""
         return f"{date.isoformat()}T{h:02d}:{mi:02d}:{s:02d}{fs}"
 
     # --- arithmetic ------------------------------------------------------------

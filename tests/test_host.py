@@ -37,6 +37,12 @@ class TestUnits:
     def test_time(self):
         t0 = pb.Time(56000.0, format="mjd")
         assert t0.isot.startswith("2012-03-14T00:00:00")
+        # the printed string rounds the whole time of day, with carry, not the fraction on its own
+        t1 = pb.Time("2020-01-01T12:34:59.000", format="isot", precision=9)
+        assert (t1 + 0.9999999996 * u.s).isot == "2020-01-01T12:35:00.000000000"
+        assert (t1 + 0.5 * u.s).isot == "2020-01-01T12:34:59.500000000"
+        t2 = pb.Time("2020-12-31T23:59:59.000", format="isot", precision=9)
+        assert (t2 + 0.99999999999 * u.s).isot == "2021-01-01T00:00:00.000000000"
         t1 = t0 + 1.5 * u.s
         assert (t1 - t0).to_value(u.s) == pytest.approx(1.5)
         assert (t0 + 86400 * u.s).mjd == pytest.approx(56001.0)

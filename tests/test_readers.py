@@ -287,6 +287,14 @@ class TestDeviceDecode:
             _hip.decode(raw, dict(lay, stride_t=3), 0, 150, 2, 1)   # a block's samples overrun into the next block
         with pytest.raises(errors):
             _hip.decode(raw, dict(lay, nbits=3), 0, 10, 2, 1)
+        # strides / block counts whose products leave 63 bits are rejected, not wrapped around into "in bounds"
+        big = 1 << 62
+        for bad in (dict(lay, stride_t=big), dict(lay, stride_c=big, stride_t=1), dict(lay, blk_stride=big, blk_samples=1),
+                    dict(lay, elem0=big, stride_t=big)):
+            with pytest.raises(errors):
+                _hip.decode(raw, bad, 0, 250, 2, 1)
+        with pytest.raises(errors):
+            _hip.decode(raw, lay, (1 << 63) - 100, 250, 2, 1)
 
 
 # ---- streaming straight from the payload bytes (pbh_dedisperse_stream_raw) -----------------------------------
