@@ -123,6 +123,9 @@ def main():
     os.dup2(2, 1)
 
     t_start = time.perf_counter()
+    if os.environ.get("PBH_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack if the run is still alive after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PBH_BENCH_WATCHDOG"]), exit=True)
 
     def mark(what):  # wall-clock trail on stderr: where a slow launch spends its time (imports, RCCL init, ...)
         log(f"[bench +{time.perf_counter() - t_start:7.1f}s] {what}")
@@ -187,7 +190,7 @@ def main():
 
     # the plan the entry point uses (its per-thread cache): for the chirp timing, the per-kernel profile and the info
     plan, _ = _plan_for(z_local, dm, band["ref_freq"], (start, stop), variant=args.variant, device=local_rank)
-    assert (plan.crop_start, plan.crop_stop) == (start, stop)
+    assert (plan.crop_start, plan.crop_stop) == (start, max(stop, start))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan.chirp_generate(coeff, 1.0 / sr, freqs, CENTER_HZ)
@@ -233,9 +236,12 @@ def main():
     if distributed and args.gather:
         try:
             from pulsarbat_amd.node import ChannelGather
+            mark("gather: setting up the destination blocks and their mappings")
             g = ChannelGather(plan.nout, NCHAN_PER_GPU, NPOL, np.complex64, local_rank, mode=args.gather)
+            mark("gather: first run")
             g.run(plan, x)
             barrier()
+            mark("gather: timed run")
             t1 = time.perf_counter()
             g.run(plan, x)     # dedispersion + delivery of the slice to the destination block(s) + closing barrier
             gather_ms = (time.perf_counter() - t1) * 1e3

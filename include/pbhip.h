@@ -191,9 +191,16 @@ int pbh_dedisperse_layout(pbh_plan* plan, const void* in_dev, int in_layout, int
  * offset / row length are even (16-byte stores); every other geometry is served through one extra pass. */
 int pbh_dedisperse_slice(pbh_plan* plan, const void* in_dev, void* out_dev, int64_t out_row_elems,
                          int64_t out_col_offset);
+/* The same with the destination's ROWS split over nparts buffers: part i receives output rows
+ * [part_row[i], part_row[i+1]) (part_row[0] = 0, part_row[nparts] = stop - start) starting at part_dev[i].  A
+ * destination block that peers map must be built from allocations of at most 2 GiB (larger ones hang in the
+ * runtime's IPC mapping on this ROCm stack): the pipeline runs once and only its last pass runs once per part. */
+int pbh_dedisperse_slices(pbh_plan* plan, const void* in_dev, int nparts, void* const* part_dev,
+                          const int64_t* part_row /* [nparts + 1] */, int64_t out_row_elems, int64_t out_col_offset);
 
 /* Sharing a device buffer between the ranks of one node (one process per GPU).  The destination rank
- * allocates with pbh_node_alloc (a whole device allocation, hence exportable), exports a 64-byte handle,
+ * allocates with pbh_node_alloc (a whole device allocation, hence exportable; at most 2 GiB each -- a larger
+ * block is several allocations, see pbh_dedisperse_slices), exports a 64-byte handle,
  * ships it to its peers by any host channel (the Python host uses torch.distributed), and each peer maps
  * it with pbh_node_import (peer access over xGMI is enabled by the mapping) and writes into it with
  * pbh_dedisperse_slice.  The exporter must keep the buffer alive until every importer has called

@@ -90,6 +90,8 @@ SIGNATURES = {
                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_dedisperse_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "pbh_dedisperse_slices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int64,
+                                        C.c_int64]),
     "pbh_dedisperse_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "pbh_place": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "pbh_node_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -437,6 +439,21 @@ class Plan:
         _check(lib().pbh_dedisperse_mix(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                                         a.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def dedisperse_slices(self, x, part_ptrs, part_rows, row_elems, col_offset):
+        """``dedisperse_slice`` into a destination whose rows are split over several buffers: part i (device pointer
+        ``part_ptrs[i]``) receives output rows ``[part_rows[i], part_rows[i+1])`` (``pbh_dedisperse_slices``)."""
+        from .device import DeviceArray
+        if not isinstance(x, DeviceArray):
+            raise TypeError("dedisperse_slices takes a device-resident input")
+        self._check_in(x)
+        self._sync_stream()
+        n = len(part_ptrs)
+        if len(part_rows) != n + 1:
+            raise ValueError("part_rows must have one more entry than part_ptrs")
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in part_ptrs])
+        rows = (C.c_int64 * (n + 1))(*[int(r) for r in part_rows])
+        _check(lib().pbh_dedisperse_slices(self._h, C.c_void_p(x.data_ptr()), n, ptrs, rows, int(row_elems), int(col_offset)))
 
     def dedisperse_slice(self, x, out_ptr, row_elems, col_offset):
         """Dedisperse device array ``x`` and write the ``(nout, nchan, npol)`` result as columns

@@ -32,6 +32,7 @@
 #define pbh_dedisperse PBH_FN(dedisperse)
 #define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
 #define pbh_dedisperse_slice PBH_FN(dedisperse_slice)
+#define pbh_dedisperse_slices PBH_FN(dedisperse_slices)
 #define pbh_dedisperse_mix PBH_FN(dedisperse_mix)
 #define pbh_place PBH_FN(place)
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
@@ -604,7 +605,22 @@ struct IoLayout {
     const double* mix_ft = nullptr;   // sample-major input: per-series mixer frequencies (device), applied by the de-interleave pass
     int64_t out_row_elems = 0;   // sample-major output: elements between consecutive rows (0 = compact, S): the rows are a
                                  // channel slice of a wider (nout, nchan_total, npol) array (pbh_dedisperse_slice)
+    // the output rows may be split over several buffers (row-chunks of a destination block, each its own allocation):
+    // part i holds output rows [part_row[i], part_row[i+1]) starting at part_ptr[i]; empty = one buffer, `out`
+    std::vector<cf*> part_ptr;
+    std::vector<int64_t> part_row;
 };
+
+// the final layout pass, once per output part (IoLayout::part_ptr) or once for the whole output
+static int launch_reinterleave_parts(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane, hipStream_t st,
+                                     int64_t opitch, const std::vector<cf*>& part_ptr, const std::vector<int64_t>& part_row) {
+    if (part_ptr.empty()) return launch_reinterleave(work, out, start, stop, S, plane, st, opitch);
+    for (size_t i = 0; i < part_ptr.size(); ++i) {
+        const int64_t r0 = part_row[i], r1 = part_row[i + 1];
+        if (r1 > r0) PBHCHECK(launch_reinterleave(work, part_ptr[i], start + r0, start + r1, S, plane, st, opitch));
+    }
+    return PBH_OK;
+}
 
 // One-tile plans (nsample <= 2^tile) whose blocks have many series run as layout pass + planar row pass + layout pass
 // instead of the single interleaved kernel (build_steps); needs the planar work buffer (allocated at plan creation).
@@ -688,8 +704,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         rp.cdiv = FR > 1 ? p->npol : 1;
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(M, rp, st); }});
         const int64_t orow = io.out_row_elems;
+        const auto pp = io.part_ptr;
+        const auto pr = io.part_row;
         steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-            return launch_reinterleave(work, out, start, stop, S, N, st, orow);
+            return launch_reinterleave_parts(work, out, start, stop, S, N, st, orow, pp, pr);
         }});
         return steps;
     }
@@ -852,8 +870,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             }});
         } else if (!out_sm) {
             const int64_t orow = io.out_row_elems;
+            const auto pp = io.part_ptr;
+            const auto pr = io.part_row;
             steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-                return launch_reinterleave(work, out, start, stop, S, N, st, orow);
+                return launch_reinterleave_parts(work, out, start, stop, S, N, st, orow, pp, pr);
             }});
         }
     } else {
@@ -2101,19 +2121,46 @@ static bool slice_fast_ok(const pbh_plan* p) {
 // The multi-GPU gather: a rank's (nout, nchan_local, npol) result is written straight into its
 // channel slice of the full-band (nout, nchan_total, npol) block -- which may live on a peer GPU (pbh_node_import) --
 // by the pipeline's last kernel, instead of transpose + all-gather + concatenate + transpose afterwards.
+int pbh_dedisperse_slices(pbh_plan* p, const void* in_dev, int nparts, void* const* part_dev, const int64_t* part_row,
+                          int64_t out_row_elems, int64_t out_col_offset);
 int pbh_dedisperse_slice(pbh_plan* p, const void* in_dev, void* out_dev, int64_t out_row_elems, int64_t out_col_offset) {
-    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p) return fail(PBH_ERR_INVALID, "NULL argument");
+    const int64_t rows[2] = {0, p->stop > p->start ? p->stop - p->start : 0};
+    void* const parts[1] = {out_dev};
+    return pbh_dedisperse_slices(p, in_dev, 1, parts, rows, out_row_elems, out_col_offset);
+}
+
+// The same with the destination's rows split over nparts buffers: part i receives output rows [part_row[i],
+// part_row[i+1]) (part_row[0] = 0, part_row[nparts] = nout) at part_dev[i], row r of the part at part_dev[i] +
+// (r - part_row[i])*out_row_elems.  A destination block larger than 2 GiB has to be several allocations when peers map
+// it (pbh_node_import hangs on larger ones with this ROCm stack); the pipeline runs once, its last pass once per part.
+int pbh_dedisperse_slices(pbh_plan* p, const void* in_dev, int nparts, void* const* part_dev, const int64_t* part_row,
+                          int64_t out_row_elems, int64_t out_col_offset) {
+    if (!p || !in_dev || !part_dev || !part_row || nparts < 1) return fail(PBH_ERR_INVALID, "NULL argument");
     if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
     if (out_col_offset < 0 || out_row_elems < out_col_offset + p->S)
         return fail(PBH_ERR_INVALID, "pbh_dedisperse_slice: the slice [offset, offset + nchan*npol) does not fit the output row");
     HIPCHECK(hipSetDevice(p->device));
     const int64_t nout = p->stop - p->start;
     if (nout <= 0) return PBH_OK;
-    cf* base = (cf*)out_dev + out_col_offset;
-    if (out_row_elems == p->S || slice_fast_ok(p)) {
-        IoLayout io;
+    if (part_row[0] != 0 || part_row[nparts] != nout) return fail(PBH_ERR_INVALID, "pbh_dedisperse_slices: the parts must cover rows [0, nout)");
+    IoLayout io;
+    for (int i = 0; i < nparts; ++i) {
+        if (part_row[i + 1] < part_row[i]) return fail(PBH_ERR_INVALID, "pbh_dedisperse_slices: part rows must not decrease");
+        if (part_row[i + 1] > part_row[i] && !part_dev[i]) return fail(PBH_ERR_INVALID, "pbh_dedisperse_slices: NULL part");
+        io.part_ptr.push_back((cf*)part_dev[i] + out_col_offset);
+        io.part_row.push_back(part_row[i]);
+    }
+    io.part_row.push_back(nout);
+    const bool compact = out_row_elems == p->S && nparts == 1;
+    if (compact || slice_fast_ok(p) || (p->N1 == 1 && p->work && single_planar_ok(p))) {
         io.out_row_elems = out_row_elems == p->S ? 0 : out_row_elems;
-        auto steps = build_steps(p, (const cf*)in_dev, base, DetectTail(), io);
+        cf* first = io.part_ptr[0];
+        if (compact) {
+            io.part_ptr.clear();
+            io.part_row.clear();
+        }
+        auto steps = build_steps(p, (const cf*)in_dev, first, DetectTail(), io);
         return run_steps(steps, p->stream);
     }
     // other pipelines (single tile, 3-pass, two-axis layout tiles, arbitrary lengths): compact result, then one placing pass
@@ -2121,7 +2168,12 @@ int pbh_dedisperse_slice(pbh_plan* p, const void* in_dev, void* out_dev, int64_t
     PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, bytes));
     auto steps = build_steps(p, (const cf*)in_dev, (cf*)p->stage_out);
     PBHCHECK(run_steps(steps, p->stream));
-    return launch_place(p->stream, (const cf*)p->stage_out, p->S, base, out_row_elems, nout, p->S);
+    for (int i = 0; i < nparts; ++i) {
+        const int64_t r0 = part_row[i], r1 = part_row[i + 1];
+        if (r1 > r0)
+            PBHCHECK(launch_place(p->stream, (const cf*)p->stage_out + r0 * p->S, p->S, io.part_ptr[i], out_row_elems, r1 - r0, p->S));
+    }
+    return PBH_OK;
 }
 
 // 2-D copy between sample-major device arrays of this build's complex dtype: nrow rows of ncol elements, row pitches

@@ -35,6 +35,7 @@
     int P##dedisperse(P##plan*, const void*, void*, int, int);                                                  \
     int P##dedisperse_layout(P##plan*, const void*, int, int64_t, void*, int, int64_t);                         \
     int P##dedisperse_slice(P##plan*, const void*, void*, int64_t, int64_t);                                    \
+    int P##dedisperse_slices(P##plan*, const void*, int, void* const*, const int64_t*, int64_t, int64_t);       \
     int P##dedisperse_mix(P##plan*, const void*, void*, const double*);                                         \
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
@@ -192,6 +193,9 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in, int il, int64_t ip, void*
 }
 int pbh_dedisperse_slice(pbh_plan* p, const void* in, void* out, int64_t row, int64_t off) {
     FORWARD(p, pbh32_dedisperse_slice(P32(p), in, out, row, off), pbh64_dedisperse_slice(P64(p), in, out, row, off));
+}
+int pbh_dedisperse_slices(pbh_plan* p, const void* in, int np, void* const* parts, const int64_t* rows, int64_t row, int64_t off) {
+    FORWARD(p, pbh32_dedisperse_slices(P32(p), in, np, parts, rows, row, off), pbh64_dedisperse_slices(P64(p), in, np, parts, rows, row, off));
 }
 int pbh_dedisperse_mix(pbh_plan* p, const void* in, void* out, const double* ft) {
     FORWARD(p, pbh32_dedisperse_mix(P32(p), in, out, ft), pbh64_dedisperse_mix(P64(p), in, out, ft));

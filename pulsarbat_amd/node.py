@@ -95,15 +95,22 @@ class PeerBuffer:
 class ChannelGather:
     """Gather of channel-sharded results by direct writes into the destination ranks' full-band blocks.
 
-    ``mode="all"``: every rank owns a full ``(nout, nchan_total, npol)`` block (what ``gather=True`` returns on
-    every rank); ``mode="root"``: only ``root`` does.  Every rank runs its plan once: the pipeline's last kernel
-    writes the rank's slice into the first destination (its own block when it has one), and ``pbh_place`` pushes
-    the slice from there to the remaining destinations.  Reusable for repeated calls of one geometry (a stream of
-    blocks): buffers and mappings are set up once.
+    ``mode="all"``: every rank ends up with the full ``(nout, nchan_total, npol)`` block (what ``gather=True`` returns
+    on every rank); ``mode="root"``: only ``root`` does.  A destination's block is a run of ROW-CHUNKS, each its own
+    allocation of at most ``chunk_bytes`` (1 GiB): mapping an allocation larger than 2 GiB into a peer process hangs in
+    this ROCm stack's IPC (measured: 2040 MiB maps in 0.1 ms, 2056 MiB never returns), and the blocks in question are
+    2 - 17 GB.  Every rank runs its plan once: the pipeline's last kernel writes the rank's channel slice into the chunks
+    of the first destination (``pbh_dedisperse_slices``; its own chunks when it is a destination), and ``pbh_place``
+    pushes the slice from there to the other destinations' chunks.  After the closing barrier a destination joins its
+    chunks into one contiguous array (a local pass at HBM speed, small beside the xGMI transfer it follows).
+    Reusable for repeated calls of one geometry (a stream of blocks): chunks and mappings are set up once.
     """
 
-    def __init__(self, nout, nchan_local, npol, dtype, device, group=None, mode="all", root=0):
+    def __init__(self, nout, nchan_local, npol, dtype, device, group=None, mode="all", root=0, chunk_bytes=None):
+        import os
         import torch.distributed as dist
+        if chunk_bytes is None:   # PBH_GATHER_CHUNK_BYTES: tests force many chunks at small sizes
+            chunk_bytes = int(os.environ.get("PBH_GATHER_CHUNK_BYTES", 1 << 30))
         if mode not in ("all", "root"):
             raise ValueError("mode must be 'all' or 'root'")
         self.group, self.mode, self.root = group, mode, int(root)
@@ -116,13 +123,20 @@ class ChannelGather:
         self.chan_lo = sum(self.counts[:self.rank])
         self.nchan_local = int(nchan_local)
         self.is_dest = mode == "all" or self.rank == self.root
-        self.own = NodeBuffer((self.nout, self.nchan_total, self.npol), self.dtype, self.device) if self.is_dest else None
+        row_bytes = self.row_elems * self.dtype.itemsize
+        rows_per = max(1, min(int(chunk_bytes), (2 << 30) - 1) // max(row_bytes, 1))
+        self.part_rows = list(range(0, self.nout, rows_per)) + [self.nout] if self.nout > 0 else [0, 0]
+        nparts = len(self.part_rows) - 1
+        self.own = None
+        if self.is_dest:
+            self.own = [NodeBuffer((self.part_rows[i + 1] - self.part_rows[i], self.nchan_total, self.npol), self.dtype,
+                                   self.device) for i in range(nparts)]
         handles = [None] * self.world
-        dist.all_gather_object(handles, self.own.handle() if self.own is not None else None, group=group)
+        dist.all_gather_object(handles, [b.handle() for b in self.own] if self.own is not None else None, group=group)
         self.peers = {}
-        for r, h in enumerate(handles):
-            if h is not None and r != self.rank:
-                self.peers[r] = PeerBuffer(h, self.device)
+        for r, hs in enumerate(handles):
+            if hs is not None and r != self.rank:
+                self.peers[r] = [PeerBuffer(h, self.device) for h in hs]
 
     @property
     def row_elems(self):
@@ -138,25 +152,39 @@ class ChannelGather:
             raise ValueError("plan geometry does not match the gather")
         off = self.chan_lo * self.npol
         ncol = self.nchan_local * self.npol
-        dests = ([self.own.ptr] if self.own is not None else []) + [p.ptr for _, p in sorted(self.peers.items())]
+        dests = ([[b.ptr for b in self.own]] if self.own is not None else []) + \
+                [[p.ptr for p in ps] for _, ps in sorted(self.peers.items())]
         if self.nout > 0 and ncol > 0:
-            plan.dedisperse_slice(x, dests[0], self.row_elems, off)
+            plan.dedisperse_slices(x, dests[0], self.part_rows, self.row_elems, off)
             esz = self.dtype.itemsize
             stream = _hip._stream_ptr(self.device)
             for d in dests[1:]:
-                _hip._check(lib.pbh_place(self.device, stream, _hip._dtype_code(self.dtype),
-                                          C.c_void_p(dests[0] + off * esz), self.row_elems,
-                                          C.c_void_p(d + off * esz), self.row_elems, self.nout, ncol))
+                for i, (src, dst) in enumerate(zip(dests[0], d)):
+                    rows = self.part_rows[i + 1] - self.part_rows[i]
+                    _hip._check(lib.pbh_place(self.device, stream, _hip._dtype_code(self.dtype),
+                                              C.c_void_p(src + off * esz), self.row_elems,
+                                              C.c_void_p(dst + off * esz), self.row_elems, rows, ncol))
         torch.cuda.synchronize(self.device)   # this rank's writes (local and peer) have landed
         dist.barrier(group=self.group)        # ... and so have everybody else's
-        return self.own.array if self.own is not None else None
+        if self.own is None:
+            return None
+        if len(self.own) == 1:
+            return DeviceArray(self.own[0].array.tensor.clone())   # (a copy: the chunks are re-used by the next run)
+        full = DeviceArray.empty((self.nout, self.nchan_total, self.npol), self.dtype, device=self.device)
+        for i, b in enumerate(self.own):
+            full.tensor[self.part_rows[i]:self.part_rows[i + 1]].copy_(b.array.tensor)
+        return full
 
     def close(self):
         import torch.distributed as dist
-        for p in getattr(self, "peers", {}).values():
-            p.close()
+        for ps in getattr(self, "peers", {}).values():
+            for p in ps:
+                p.close()
         self.peers = {}
         try:
-            dist.barrier(group=self.group)   # nobody still has this rank's block mapped when it may be freed
+            dist.barrier(group=self.group)   # nobody still has this rank's chunks mapped when they may be freed
         except Exception:
             pass
+        for b in (getattr(self, "own", None) or []):
+            b.close()
+        self.own = None

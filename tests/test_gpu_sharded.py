@@ -171,6 +171,8 @@ def _world2_worker(rank, world, port, q, nchan):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)   # both ranks share the one GPU of the test box; the mappings are real IPC all the same
+    if nchan == 8:
+        os.environ["PBH_GATHER_CHUNK_BYTES"] = str(3 << 20)   # the destination blocks become a dozen row-chunks
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         shape, dm, sr, fc = _small_case()
