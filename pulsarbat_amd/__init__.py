@@ -20,7 +20,9 @@ from . import fft
 from . import contrib
 from . import utils
 from . import readers
+from . import shard     # channel sharding across the GPUs of a node (one process per GPU)
+from . import node      # node-level buffers and the peer-write gather behind shard
 
-__all__ = ["fft", "contrib", "utils", "readers", "units", "Time", "DeviceArray", "InvalidSignalError"]
+__all__ = ["fft", "contrib", "utils", "readers", "shard", "node", "units", "Time", "DeviceArray", "InvalidSignalError"]
 __all__.extend(core.__all__)
 __all__.extend(transforms.__all__)
