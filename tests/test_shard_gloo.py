@@ -84,3 +84,42 @@ def test_sharded_equals_full_world2():
         assert np.allclose(freqs, fwant)
         assert abs(dt - start / SR) < 1e-12
         assert lshape == (stop - start, SHAPE[1] // world, SHAPE[2])
+
+
+def _scatter_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    counts = [3, 2]                                                          # ragged channel blocks
+    full = (rng.standard_normal((256, 5, 2)) + 1j * rng.standard_normal((256, 5, 2))).astype(np.complex64)
+    shared = full[:, :1]                                                     # one row for every channel: a broadcast
+    got = shard._scatter_chirp(full if rank == 1 else None, 1, counts, rank, None, 0)
+    got1 = shard._scatter_chirp(shared if rank == 0 else None, 0, counts, rank, None, 0)
+    vec = shard._scatter_chirp(full[:, 0, 0] if rank == 0 else None, 0, counts, rank, None, 0)   # (N,) -> (N, 1)
+    q.put((rank, got, got1, vec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_user_chirp_scatter_world2():
+    """X1 on the host channel: rank 1 holds the full-band chirp, every rank receives its (ragged) channel block; a chirp
+    with one channel row is broadcast whole (reference dedispersion.py:121-124, sharded)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(1)
+    full = (rng.standard_normal((256, 5, 2)) + 1j * rng.standard_normal((256, 5, 2))).astype(np.complex64)
+    for rank, got, got1, vec in results:
+        lo, hi = (0, 3) if rank == 0 else (3, 5)
+        assert got.shape == (256, hi - lo, 2) and np.array_equal(got, full[:, lo:hi])
+        assert np.array_equal(got1, full[:, :1])
+        assert vec.shape == (256, 1) and np.array_equal(vec[:, 0], full[:, 0, 0])
