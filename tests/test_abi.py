@@ -101,3 +101,16 @@ def test_c_consumer_runs_the_hot_path(tmp_path):
     assert "plan_create: 0" in r.stdout and "chirp_generate: 0" in r.stdout and "dedisperse: 0" in r.stdout
     val = float(r.stdout.split("abs2 of one output sample:")[1].split()[0])
     assert abs(val - 1.0) < 1e-4
+
+
+def test_node_alloc_refuses_buffers_that_would_hang_a_peer():
+    """pbh_node_alloc: allocations that another process may map are limited to 2 GiB - 1 (a larger one makes the peer's
+    hipIpcOpenMemHandle hang on this ROCm stack); the refusal needs no GPU."""
+    import ctypes as C
+    from pulsarbat_amd import _hip
+    lib = _hip.lib()
+    ptr = C.c_void_p()
+    rc = lib.pbh_node_alloc(0, (1 << 31), C.byref(ptr))
+    assert rc == -2 and not ptr.value            # PBH_ERR_UNSUPPORTED
+    assert b"2 GiB" in lib.pbh_last_error()
+    assert lib.pbh_node_alloc(0, 0, C.byref(ptr)) == -1

@@ -316,3 +316,34 @@ class TestUserChirpGenerality:
                                         pol_type="linear")
         y64 = pb.coherent_dedispersion(z64, pb.DM(dm), chirp=chirp)
         assert y64.dtype == np.complex128 and per_series_l2(y64, want).max() < 1e-6
+
+
+def test_config3_full_size_stream():
+    """BASELINE configs[3] at full size: 2^28 samples x 8 chan x 2 pol streamed from host memory in 2^22-sample chunks
+    (overlap-save, hop 615 915, 430 chunks, double-buffered hipMemcpyAsync); three of the chunks against the oracle, the
+    chunk layout against the concatenate-of-reference-calls recipe (transforms.py:59-148)."""
+    from pulsarbat_amd import _hip
+    total, n, nchan, npol, dm, band, fc = 1 << 28, 1 << 22, 8, 2, 56.77, 400e6, 1.4e9
+    sr = band / nchan
+    start, stop = orc.crop_bounds(dm, n, nchan, sr, fc, fc)
+    assert (start, stop) == (1408404, 2024319)
+    hop = stop - start
+    nchunk = (total - n) // hop + 1
+    assert nchunk == 430
+    # 34 GB of input without 34 GB worth of random numbers: one random 2^24-sample block, repeated with a different
+    # complex factor per repeat (the hop is not commensurate with the block, so every chunk sees different data)
+    base = orc.synthetic_block((1 << 24, nchan, npol), 20260004)
+    x = np.empty((total, nchan, npol), np.complex64)
+    for k in range(total >> 24):
+        np.multiply(base, np.complex64(np.exp(0.37j * k) * (1 + 0.01 * k)), out=x[k << 24:(k + 1) << 24])
+    freqs = orc.channel_freqs(fc, sr, nchan)
+    with _hip.Plan(n, nchan, npol, start, stop, device=0) as plan:
+        plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, fc)
+        y, ms = plan.dedisperse_stream(x)
+    assert y.shape == (nchunk * hop, nchan, npol) and ms > 0
+    for k in (0, 215, 429):
+        want = oracle_shard(x[k * hop:k * hop + n], dm, sr, freqs, fc, start, stop)
+        err = per_series_l2(y[k * hop:(k + 1) * hop], want)
+        assert err.max() < RTOL_L2, f"chunk {k}: per-series relative L2 {err}"
+    print(f"configs[3] full size: {ms:.0f} ms, {nchunk * n * nchan * npol / ms / 1e3:.0f} Msamples/s in, "
+          f"{y.shape[0] * nchan * npol / ms / 1e3:.0f} Msamples/s valid, H2D {nchunk * n * nchan * npol * 8 / ms / 1e6:.1f} GB/s")
