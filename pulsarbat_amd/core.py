@@ -112,37 +112,38 @@ class Signal(np.lib.mixins.NDArrayOperatorsMixin):
     def __len__(self):
         return len(self.data)
 
-    # --- printing (core.py:124-147) ------------------------------------------------
+    # --- printing: the text layout is the reference's (core.py:124-147), the assembly is ours --------------
+    def _attr_lines(self):
+        """(label, value) pairs shown under the header; subclasses extend the list."""
+        began = self.start_time.isot if self.start_time is not None else "N/A"
+        return [("Sample rate", self.sample_rate), ("Time length", self.time_length), ("Start time", began)]
+
     def _attr_repr(self):
-        st = "N/A" if self.start_time is None else self.start_time.isot
-        return (f"Sample rate: {self.sample_rate}\n"
-                f"Time length: {self.time_length}\n"
-                f"Start time: {st}\n")
+        return "".join(f"{label}: {value}\n" for label, value in self._attr_lines())
 
     def __str__(self):
-        sig = f"{type(self).__name__} @ {hex(id(self))}"
-        c = type(self.data)
-        out = f"{sig}\n{'-' * len(sig)}\n"
-        out += f"Data Container: {c.__module__}.{c.__name__}<shape={self.shape}, dtype={self.dtype}>\n"
-        out += self._attr_repr()
+        title = f"{type(self).__name__} @ {hex(id(self))}"
+        holder = type(self.data)
+        parts = [title, "-" * len(title),
+                 f"Data Container: {holder.__module__}.{holder.__name__}<shape={self.shape}, dtype={self.dtype}>",
+                 self._attr_repr().rstrip("\n")]
         if self.meta is not None:
-            out += "\nMeta\n----\n" + pprint.pformat(self.meta, sort_dicts=False, depth=2)
-        return out.strip()
+            parts += ["", "Meta", "----", pprint.pformat(self.meta, sort_dicts=False, depth=2)]
+        return "\n".join(parts).strip()
 
     def __repr__(self):
-        return (f"pulsarbat.{type(self).__name__}<shape={self.shape}, dtype={self.dtype}>"
-                f" @ {hex(id(self))}")
+        return f"pulsarbat.{type(self).__name__}<shape={self.shape}, dtype={self.dtype}> @ {hex(id(self))}"
 
-    # --- slicing (core.py:155-176) -----------------------------------------------------
+    # --- slicing: what a time slice does to the metadata (core.py:155-176) ---------------------------------
     def _time_slice(self, index):
-        sl = slice(*index.indices(self.shape[0]))
-        assert sl.step > 0, "Time axis slicing does not support negative step"
-        kw = {}
-        if sl.step > 1:
-            kw["sample_rate"] = self.sample_rate / sl.step
-        if self.start_time is not None:
-            kw["start_time"] = self.start_time + sl.start / self.sample_rate
-        return kw
+        first, _, step = index.indices(self.shape[0])
+        assert step > 0, "Time axis slicing does not support negative step"
+        changes = {}
+        if step != 1:                       # every step-th sample: a lower sample rate
+            changes["sample_rate"] = self.sample_rate / step
+        if self.start_time is not None:     # the first kept sample sets the new start
+            changes["start_time"] = self.start_time + first / self.sample_rate
+        return changes
 
     _sliceable_axes = 1
 
@@ -150,23 +151,22 @@ class Signal(np.lib.mixins.NDArrayOperatorsMixin):
         return self._time_slice(index[0])
 
     def __getitem__(self, index):
-        if not isinstance(index, tuple):
-            index = (index,)
+        index = index if isinstance(index, tuple) else (index,)
         n = self._sliceable_axes
-        if not all(isinstance(a, slice) for a in index[:n]):
+        if any(not isinstance(a, slice) for a in index[:n]):
             names = "time axis" if n == 1 else "time and frequency axes"
             raise IndexError(f"Only supports slicing on {names}.")
         return type(self).like(self, self.data[index], **self._slice_kwargs(index))
 
     def get_axis(self, axis):
-        """Axis number from an integer or an axis label (core.py:178-188)."""
-        try:
-            axis = operator.index(axis)
-        except TypeError:
-            axis = self.axes_labels.get(axis, None)
-        if axis is None or not (-self.ndim <= axis < self.ndim):
+        """Axis number of an integer (negative counts from the end) or of an axis label."""
+        if isinstance(axis, str) or not hasattr(axis, "__index__"):
+            number = self.axes_labels.get(axis)
+        else:
+            number = operator.index(axis)
+        if number is None or number >= self.ndim or number < -self.ndim:
             raise ValueError("Invalid axis.")
-        return axis
+        return number
 
     # --- attributes ---------------------------------------------------------------------
     @property
@@ -178,11 +178,13 @@ class Signal(np.lib.mixins.NDArrayOperatorsMixin):
         return self._meta
 
     @meta.setter
-    def meta(self, meta):
-        try:
-            self._meta = None if meta is None else dict(meta)
-        except Exception:
-            raise ValueError("meta must be a dict.")
+    def meta(self, value):
+        if value is not None:
+            try:
+                value = dict(value)
+            except (TypeError, ValueError):
+                raise ValueError("meta must be a dict.") from None
+        self._meta = value
 
     @property
     def data(self):
