@@ -950,6 +950,88 @@ __global__ __launch_bounds__(kTilePoints / R) void k_small(SmallParams p) {
     }
 }
 
+// ---- contrib.stft, forward, with a linearised store ---------------------------------------------------------------------
+// k_small's stft mode stores every bin from the lane that computed it: 8- or 16-byte pieces 1 KiB apart, a 128-byte line
+// of the channelised block filled by eight different waves.  The lines do not always survive in L2 until they are
+// complete: rocprofv3 counts 6.2 GB of HBM traffic for 4.3 GB of algorithmic bytes (nperseg 64, 16 series).  But a
+// tile's output is ONE contiguous block of the channelised array -- G whole segments x all series (tile/M >= S), or all
+// bins of tile/M series of one segment -- so the outputs take one more trip through LDS, laid out in output order, and
+// leave as 16-byte stores of consecutive addresses.
+struct StftFwdParams {
+    const cf* in;      // (nseg*M, S) sample-major
+    cf* out;           // (nseg, nchan*M, E) sample-major
+    const cf* tw16k;
+    int S, E;          // series (nchan*E), inner elements per channel
+    int SB, G;         // series per tile (S when a tile spans whole segments), segments per tile; SB*G <= tile/M
+    int64_t nseg;
+    real scale;        // 1/M
+};
+
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_stft_fwd(StftFwdParams p) {
+    constexpr int F = kTilePoints / M;
+    constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;
+    constexpr int NT = kTilePoints / R;
+    static_assert(F >= 16 && F <= NT, "k_stft_fwd: segment length out of range");
+    typedef real vec4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int f = tid % F, tau = tid / F;
+    const int j = f % p.SB, sl = f / p.SB;                 // series within the tile's subset, segment within the tile
+    const bool col_ok = sl < p.G;                          // (SB*G may be less than F when S is not a power of two)
+    const int q0 = blockIdx.x * p.SB;
+    const int64_t g0 = (int64_t)blockIdx.y * p.G;
+    const bool valid = col_ok && g0 + sl < p.nseg;
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+
+    const int64_t nleft = p.nseg - g0 < p.G ? p.nseg - g0 : p.G;
+    const rsrc_t ri = make_rsrc(p.in + (g0 * M) * (int64_t)p.S + q0, (uint32_t)((nleft * M * p.S - q0) * (int64_t)sizeof(cf)));
+    const int voff = valid ? (int)(((int64_t)sl * M * p.S + (int64_t)tau * p.S + j) * (int64_t)sizeof(cf)) : 0x7ffffff0;
+    const int step = MR * p.S * (int)sizeof(cf);
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = buf_load(ri, voff, i * step);
+    fft_tile<M, 1, R, -1, F, PAD>(v, lds, tau, f, w);
+    __syncthreads();
+    // staging in output order: element (sl, channel cl of the subset, shifted bin ks, e) at ((sl*CB + cl)*M + ks)*E + e, every
+    // channel block (M*E elements) shifted by 2 slots so that the 32 lanes of a half-wave fall into different banks
+    const int CB = p.SB / p.E;                             // channels in the tile's subset
+    const int cl = j / p.E, e = j - cl * p.E;
+    const int blk = sl * CB + cl;
+    cf* mine = lds + (int64_t)blk * (M * p.E + 2) + e;
+    if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int k = tau + i * MR;
+            mine[(k ^ (M / 2)) * p.E] = make_cf(v[i].x * p.scale, v[i].y * p.scale);
+        }
+    }
+    __syncthreads();
+    // the tile's output: for every segment of the tile, CB channels x M bins x E elements, contiguous from
+    // ((g0 + sl)*nchan + c0)*M*E;  linear element o of the tile = (segment ss, offset within its CB*M*E run)
+    const int run = CB * M * p.E;                          // contiguous elements per segment
+    const int total = (int)nleft * run;
+    const int64_t seg_pitch = (int64_t)p.S * M;            // elements per segment of the channelised block
+    cf* obase = p.out + g0 * seg_pitch + (int64_t)(q0 / p.E) * M * p.E;
+    for (int o = 2 * tid; o < total; o += 2 * NT) {        // two elements (16 bytes) per thread and round
+        const int ss = o / run, r = o - ss * run;
+        const int b = ss * CB + r / (M * p.E);
+        const cf* src = lds + (int64_t)b * (M * p.E + 2) + (r % (M * p.E));
+        const cf a0 = src[0], a1 = src[1];
+        vec4 x;
+        x[0] = a0.x; x[1] = a0.y; x[2] = a1.x; x[3] = a1.y;
+        *reinterpret_cast<vec4*>(obase + (int64_t)ss * seg_pitch + r) = x;
+    }
+}
+
+// (The mirrored form for istft -- linear 16-byte loads of the channelised block into LDS -- was measured and is slower than
+//  k_small's direct loads, 0.75 vs 0.60 ms at nperseg 32: partial-line READS are cheap, it is the partial-line writes that
+//  cost; istft keeps k_small.)
+
 // ---- contrib.stft written series-major: the channeliser in front of coherent_dedispersion ----------------------------
 // stft -> coherent_dedispersion is the typical pipeline: the channelised block is "hundreds of
 // narrow series" that the dedispersion's first pass would de-interleave again.  This kernel writes the channeliser's

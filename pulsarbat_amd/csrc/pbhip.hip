@@ -2526,6 +2526,16 @@ static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, i
     return PBH_OK;
 }
 
+// forward stft through k_stft_fwd: power-of-two segments of at most tile/16 points whose tiles cover whole segments (S <=
+// tile/n) or whole channels of one segment (tile/n divides S and holds whole channels)
+static bool stft_linear_ok(int64_t n, int64_t S, int inner) {
+    static const bool on = [] { const char* e = getenv("PBH_STFT_LINEAR"); return e ? atoi(e) != 0 : true; }();
+    if (!on || !is_pow2(n) || n < PBH_R || n * 32 > kTilePoints) return false;   // (at tile/16 the plain kernel is as fast or faster)
+    const int64_t F = kTilePoints / n;
+    if (S <= F) return true;
+    return S % F == 0 && F % inner == 0 && n * S * (int64_t)sizeof(cf) < 0x7fffffffLL;
+}
+
 static bool stft_pair_enabled() {
     static const bool on = [] { const char* e = getenv("PBH_STFT_PAIR"); return e ? atoi(e) != 0 : true; }();
     return on;
@@ -2676,6 +2686,30 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
                                  inverse ? (real)1 : (real)(1.0 / (double)n)};
                 hipLaunchKernelGGL(kern, dim3((unsigned)(S / 2), (unsigned)cnt), dim3(kTilePoints / PBH_R), lds_tile_bytes<true>(), st, sp);
                 if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "k_seg_pair failed to launch");
+            }
+        } else if (rc == PBH_OK && !inverse && stft_linear_ok(n, S, inner)) {
+            // forward, nperseg <= tile/32: the channelised side is written through LDS in its own order (k_stft_fwd)
+            const int64_t F = kTilePoints / n;
+            StftFwdParams sp{din, dout, tw, (int)S, inner, 0, 0, nseg, (real)(1.0 / (double)n)};
+            if (S <= F) { sp.SB = (int)S; sp.G = (int)(F / S); } else { sp.SB = (int)F; sp.G = 1; }
+            const int64_t ngrp = (nseg + sp.G - 1) / sp.G;
+            for (int64_t y0 = 0; y0 < ngrp && rc == PBH_OK; y0 += 65535) {
+                const int64_t cnt = ngrp - y0 < 65535 ? ngrp - y0 : 65535;
+                StftFwdParams q = sp;
+                q.in = din + y0 * sp.G * n * S;
+                q.out = dout + y0 * sp.G * n * S;
+                q.nseg = nseg - y0 * sp.G;
+                const size_t ldsb = lds_tile_bytes<false>() + 8192 + 64;
+                switch ((int)n) {
+#define X(m) case m: rc = launch_tile_kernel(k_stft_fwd<m, PBH_R>, q, S / sp.SB, kTilePoints / PBH_R, st, ldsb, (unsigned)cnt); break;
+#ifdef PBH_F64
+                    X(16) X(32) X(64) X(128) X(256)
+#else
+                    X(32) X(64) X(128) X(256) X(512)
+#endif
+#undef X
+                    default: rc = fail(PBH_ERR_STATE, "k_stft_fwd: unexpected segment length");
+                }
             }
         } else if (rc == PBH_OK) {
             // a tile holds F = tile/n columns: with F > S it spans F/S whole segments; grid.y walks the
