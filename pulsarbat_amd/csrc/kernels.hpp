@@ -603,7 +603,10 @@ struct RowpParams {
 
 template <int M, int R>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
-    static_assert(M == kTilePoints, "k_rowp: one row per tile");
+    // A tile is FR = 2^tile / M consecutive rows (k1 values) of one series: one contiguous block of 2^tile elements, like the
+    // one-row tile of M = 2^tile; the unit of work is the block of a (channel, k1 group) with its polarisations one after
+    // the other, the phase block (2^tile floats, same order) loaded once.  N1 must be a multiple of FR.
+    constexpr int FR = kTilePoints / M;
     constexpr int MR = M / R;
     constexpr int STEP = MR * (int)sizeof(cf), PSTEP = MR * (int)sizeof(float);
     constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);
@@ -611,9 +614,11 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
     cf* lds = reinterpret_cast<cf*>(smem);
     unsigned* slot = reinterpret_cast<unsigned*>(smem + lds_tile_bytes<true>());
 
-    const int tau = threadIdx.x;
-    const int voff = tau * (int)sizeof(cf), pvoff = tau * (int)sizeof(float);
-    const uint32_t npair = (uint32_t)p.nchan * (uint32_t)p.N1;
+    const int tau = threadIdx.x % MR, frow = threadIdx.x / MR;
+    const int fofs = frow * M;
+    const int voff = (fofs + tau) * (int)sizeof(cf), pvoff = (fofs + tau) * (int)sizeof(float);
+    const uint32_t NB = (uint32_t)p.N1 / FR;                  // k1 groups per series
+    const uint32_t npair = (uint32_t)p.nchan * NB;
     const uint32_t G = gridDim.x;
 
     cf w[tw_seeds_or1(M, R)];
@@ -621,9 +626,9 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
 
     auto row_rsrc = [&](uint32_t u, int pol) {
         if (u >= npair) return make_rsrc(p.data, 0);
-        const uint32_t chan = u / (uint32_t)p.N1, k1 = u - chan * (uint32_t)p.N1;
-        const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + k1;
-        return make_rsrc(p.data + row * M, (uint32_t)(M * sizeof(cf)));
+        const uint32_t chan = u / NB, kb = u - chan * NB;
+        const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + (int64_t)kb * FR;
+        return make_rsrc(p.data + row * M, (uint32_t)(kTilePoints * sizeof(cf)));
     };
 
     uint32_t u = blockIdx.x;
@@ -641,19 +646,19 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
         launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
         if (pol == 0) {   // wave-uniform: a new pair -- its phase row, and the index of the pair after next
             uint32_t up = u;
-            if (p.cP > 1) {
+            if (FR == 1 && p.cP > 1) {
                 const uint32_t ch = u / (uint32_t)p.N1, k1d = u - ch * (uint32_t)p.N1;
                 up = ch * (uint32_t)p.N1 + (k1d % (uint32_t)p.cP) * (uint32_t)(p.N1 / p.cP) + k1d / (uint32_t)p.cP;
             }
-            const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * M, (uint32_t)(M * sizeof(float)));
+            const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * kTilePoints, (uint32_t)(kTilePoints * sizeof(float)));
 #pragma unroll
             for (int i = 0; i < R; ++i)
                 ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));
             fetched = unx + G;
-            if (tau == 0 && p.counter) fetched = 2 * G + atomicAdd(p.counter, 1u);
+            if (threadIdx.x == 0 && p.counter) fetched = 2 * G + atomicAdd(p.counter, 1u);
         }
-        fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, 0, w);
-        if (pol == 0 && tau == 0) slot[0] = fetched;
+        fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, fofs, w);
+        if (pol == 0 && threadIdx.x == 0) slot[0] = fetched;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const cf c = make_cf(__builtin_amdgcn_cosf(ph[i]) * p.scale, __builtin_amdgcn_sinf(ph[i]) * p.scale);
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
                 __builtin_amdgcn_sched_barrier(0x38E);
             }
         };
-        fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, 0, w, hk);
+        fft_tile<M, 1, R, +1, 1, true, false, false>(v, lds, tau, fofs, w, hk);
 #pragma unroll
         for (int k = 0; k < R; ++k)
             if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }

@@ -369,10 +369,21 @@ static bool row_phase_enabled() {
     static const bool on = [] { const char* e = getenv("PBH_ROW_PHASE"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
-static int launch_rowp(RowpParams prm, hipStream_t st) {
-    int64_t tiles = (int64_t)prm.nchan * prm.N1;
+// rows of M = N2 points, 2^tile / M of them (consecutive k1 of one series) per tile
+static bool rowp_ok(int N1, int N2) {
+    const int FR = kTilePoints / N2;
+    return N2 >= 1024 && N2 <= kTilePoints && FR >= 1 && N1 % FR == 0;
+}
+static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
+    const int FR = kTilePoints / M;
+    int64_t tiles = (int64_t)prm.nchan * (prm.N1 / FR);
     if (tiles > row_grid()) tiles = row_grid();
-    return launch_tile_kernel(k_rowp<kTilePoints, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+    switch (M) {
+#define X(m) case m: return launch_tile_kernel(k_rowp<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+        FOR_ROW_M(X)
+#undef X
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "phase row pass length " + std::to_string(M));
 }
 #endif
 
@@ -803,7 +814,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colq<OP_FWD_TW>(Q, a, st); }});
                 RowpParams r{work + (int64_t)s0 * N, p->chirp_phase + (int64_t)(s0 / npol) * N, p->tw16k, 1, N1, unit,
                              (real)(1.0 / (double)p->N), ctr + ci++};
-                steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(r, st); }});
+                steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, r, st); }});
                 ColpParams b = cp3;
                 b.data = work + (int64_t)s0 * N;
                 b.S = unit;
@@ -819,7 +830,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
             rpp.cP = chirp_split;
-            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(rpp, st); }});
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
@@ -887,7 +898,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N),
                            reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
-            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(rpp, st); }});
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
@@ -1606,7 +1617,7 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     p->has_phase = false;
 #ifndef PBH_F64
     // the fused row pass of multi-pass float32 plans reads the chirp as a phase (k_rowp)
-    if (p->N1 > 1 && p->N2 == kTilePoints && p->perm_w == 0 && !p->bsL) {
+    if (p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
         p->has_phase = true;
@@ -1684,7 +1695,7 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     bool phase = false;
 #ifndef PBH_F64
     // the time-shift ramp has unit magnitude: the row pass can read it as a phase, like a generated chirp
-    if (mode == 0 && p->N1 > 1 && p->N2 == kTilePoints && p->perm_w == 0 && !p->bsL) {
+    if (mode == 0 && p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
         phase = true;
