@@ -4,7 +4,11 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 import pulsarbat_amd as pb
 from pulsarbat_amd import units as u, _hip
+from pulsarbat_amd import shard
 from pulsarbat_amd.transforms.dedispersion import clear_plan_cache
+import os, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+dist.init_process_group("gloo", rank=0, world_size=1)
 
 def free():
     gc.collect()
@@ -29,6 +33,14 @@ def one_round(k):
     _hip.decode(raw, lay, 0, n, 2, 2, conj=np.array([[1, 0], [0, 1]], bool))
     pb.coherent_dedispersion_stream(pb.DualPolarizationSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz, pol_type="linear"),
                                     pb.DM(2.0), chunk=1 << 15)
+    # round-2 entry points: fused channelise + dedisperse, user chirps (per polarisation), the sharded call with its gather
+    if n in (1 << 18, 1 << 20):
+        pb.contrib.stft_dedisperse(z, pb.DM(0.5), nperseg=[32, 64][k % 2])
+    c = np.exp(2j * np.pi * rng.random((n, 2, 2))).astype(np.complex64)
+    pb.coherent_dedispersion(z, pb.DM(2.0), chirp=c)
+    zl = shard.shard_signal(z, 2, k % 2)
+    shard.coherent_dedispersion_sharded(zl, pb.DM(2.0), band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq,
+                                        gather=[False, True, "root"][k % 3])
 
 one_round(0); one_round(1); one_round(2); one_round(3)
 clear_plan_cache()
