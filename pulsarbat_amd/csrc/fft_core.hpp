@@ -209,30 +209,44 @@ struct Dft<7, DIR> {
 // Stages for length M with R points per thread: radix R while at least R remain, then one
 // stage of the remainder.
 constexpr int kMaxRadix = 32;  // largest in-register DFT; R = 64 points per thread means two radix-32 butterflies
-constexpr int stage_radix(int M, int NS, int R) {
-    return (M / NS >= (R < kMaxRadix ? R : kMaxRadix)) ? (R < kMaxRadix ? R : kMaxRadix) : (M / NS);
+// ORD = 0: radix R while at least R remain, then one stage of the remainder (32, 32, 16 for 2^14 points at R = 32).
+// ORD = 1: the remainder FIRST (16, 32, 32): with PIN (below) the first stage's two radix-16 butterflies of a thread start from
+//          ADJACENT points, so a row tile can be loaded with 16-byte accesses.
+constexpr int small_factor(int M, int Rm) {
+    int m = M;
+    while (m >= Rm && m % Rm == 0) m /= Rm;
+    return m;
+}
+constexpr int stage_radix(int M, int NS, int R, int ORD = 0) {
+    const int Rm = R < kMaxRadix ? R : kMaxRadix;
+    if (ORD == 1) return (NS == 1 && small_factor(M, Rm) > 1) ? small_factor(M, Rm) : Rm;
+    return (M / NS >= Rm) ? Rm : (M / NS);
 }
 // number of stage-twiddle seeds a thread needs for the stages starting at sub-length NS
 // (the last stage's butterflies q = 0..NB-1 share one seed: W_M^{(tau + q M/R) j} = (W_M^tau)^j W_R^{q j},
-//  and W_R^{q j} is a compile-time constant)
-constexpr int stage_seeds(int M, int NS, int R) {
-    return NS <= 1 ? 0 : ((NS * stage_radix(M, NS, R) == M && R <= kMaxRadix) ? 1 : R / stage_radix(M, NS, R));
+//  and W_R^{q j} is a compile-time constant; with POUT their bases are NB tau + q and each has its own seed)
+constexpr int stage_seeds(int M, int NS, int R, int ORD = 0, bool POUT = false) {
+    return NS <= 1 ? 0
+                   : ((NS * stage_radix(M, NS, R, ORD) == M && R <= kMaxRadix && !(POUT && R / stage_radix(M, NS, R, ORD) > 1))
+                          ? 1 : R / stage_radix(M, NS, R, ORD));
 }
-constexpr int tw_seeds(int M, int NS, int R) {
-    return NS >= M ? 0 : (stage_seeds(M, NS, R) + tw_seeds(M, NS * stage_radix(M, NS, R), R));
+constexpr int tw_seeds(int M, int NS, int R, int ORD = 0, bool POUT = false) {
+    return NS >= M ? 0 : (stage_seeds(M, NS, R, ORD, POUT) + tw_seeds(M, NS * stage_radix(M, NS, R, ORD), R, ORD, POUT));
 }
-constexpr int tw_seeds_or1(int M, int R) { return tw_seeds(M, 1, R) > 0 ? tw_seeds(M, 1, R) : 1; }
+constexpr int tw_seeds_or1(int M, int R, int ORD = 0, bool POUT = false) {
+    return tw_seeds(M, 1, R, ORD, POUT) > 0 ? tw_seeds(M, 1, R, ORD, POUT) : 1;
+}
 // index of the stage that starts at sub-length NS, and the number of stages
-constexpr int stage_index(int M, int NS, int R) {
+constexpr int stage_index(int M, int NS, int R, int ORD = 0) {
     int s = 0;
-    for (int ns = 1; ns < NS; ns *= stage_radix(M, ns, R)) ++s;
+    for (int ns = 1; ns < NS; ns *= stage_radix(M, ns, R, ORD)) ++s;
     return s;
 }
-constexpr int stage_count(int M, int R) { return stage_index(M, M, R); }
+constexpr int stage_count(int M, int R, int ORD = 0) { return stage_index(M, M, R, ORD); }
 // sub-length at which the last stage starts
-constexpr int last_stage_ns(int M, int R) {
+constexpr int last_stage_ns(int M, int R, int ORD = 0) {
     int ns = 1;
-    while (ns * stage_radix(M, ns, R) < M) ns *= stage_radix(M, ns, R);
+    while (ns * stage_radix(M, ns, R, ORD) < M) ns *= stage_radix(M, ns, R, ORD);
     return ns;
 }
 
@@ -257,22 +271,23 @@ constexpr int lds_tile_bytes() {
 }
 
 // Load the per-stage twiddle seeds W_{NS*RAD}^{k} for this thread (global table, L2-resident).
-template <int M, int NS, int R>
+template <int M, int NS, int R, int ORD = 0, bool POUT = false>
 __device__ __forceinline__ void load_tw_seeds(cf* w, int tau, const cf* __restrict__ tw) {
     if constexpr (NS < M) {
-        constexpr int RAD = stage_radix(M, NS, R);
+        constexpr int RAD = stage_radix(M, NS, R, ORD);
         constexpr int NB = R / RAD;
         if constexpr (NS > 1) {
-            constexpr int NSEED = stage_seeds(M, NS, R);
+            constexpr int NSEED = stage_seeds(M, NS, R, ORD, POUT);
+            constexpr bool PAIRS = POUT && NS * RAD == M && NB > 1;   // last stage, bases NB tau + q
 #pragma unroll
             for (int q = 0; q < NSEED; ++q) {
-                int jb = tau + q * (M / R);
+                int jb = PAIRS ? NB * tau + q : tau + q * (M / R);
                 int k = jb & (NS - 1);
                 w[q] = tw[k * (kTwTable / (NS * RAD))];
             }
-            load_tw_seeds<M, NS * RAD, R>(w + NSEED, tau, tw);
+            load_tw_seeds<M, NS * RAD, R, ORD, POUT>(w + NSEED, tau, tw);
         } else {
-            load_tw_seeds<M, NS * RAD, R>(w, tau, tw);
+            load_tw_seeds<M, NS * RAD, R, ORD, POUT>(w, tau, tw);
         }
     }
 }
@@ -348,24 +363,31 @@ struct tick_tag {};  // hk(stage, tick_tag{}) runs after every sub-transform of 
 template <int V>
 using ic = std::integral_constant<int, V>;
 
-template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false, bool WSYNC = false, class HK = NoHook>
+// ORD: stage order (stage_radix).  PIN: the FIRST stage's NB butterflies of a thread have the adjacent bases NB tau + q
+// (the caller loads v[q + j NB] = x[NB tau + q + j M/RAD]: NB consecutive points per access) instead of tau + q M/R.
+// POUT: the same for the LAST stage: the thread ends up with v[q + u NB] = X[NB tau + q + u M/RAD] -- NB consecutive
+// outputs per store; the exchange in front of that stage hands every thread the inputs of those butterflies.
+template <int M, int NS, int R, int DIR, int PS, bool PAD, bool XS = false, bool WSYNC = false, class HK = NoHook,
+          int ORD = 0, bool PIN = false, bool POUT = false>
 __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs, const cf* w, HK hk = HK{}) {
     if constexpr (NS < M) {
-        constexpr int RAD = stage_radix(M, NS, R);
+        constexpr int RAD = stage_radix(M, NS, R, ORD);
         constexpr int NB = R / RAD;
         constexpr int MR = M / R;
         constexpr bool LAST = (NS * RAD == M);
-        constexpr int SI = stage_index(M, NS, R);
+        constexpr int SI = stage_index(M, NS, R, ORD);
+        constexpr bool PAIRS = NB > 1 && ((PIN && NS == 1) || (POUT && LAST));   // bases NB tau + q in this stage
+        static_assert(!(PIN || POUT) || (!XS && !WSYNC), "pair-adjacent stages: plain exchange only");
         hk(ic<SI>{}, ic<-1>{});
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             cf t[RAD];
 #pragma unroll
             for (int j = 0; j < RAD; ++j) t[j] = v[q + j * NB];
-            int jb = tau + q * MR;
+            int jb = PAIRS ? NB * tau + q : tau + q * MR;
             int k = jb & (NS - 1);
             if constexpr (NS > 1) {
-                constexpr bool ONE_SEED = LAST && NB > 1 && R <= kMaxRadix;
+                constexpr bool ONE_SEED = LAST && NB > 1 && R <= kMaxRadix && !PAIRS;
                 cf w1 = w[ONE_SEED ? 0 : q];
                 if (DIR > 0) w1 = cconj(w1);
                 apply_powers<RAD>(t, w1);
@@ -389,7 +411,7 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 const int base = (jb - k) * RAD + k;
                 // linear form is exact when the step is a multiple of 32 slots, or when it is the
                 // first stage of a row tile (base*PS+fofs is a multiple of RAD, u < RAD <= 32)
-                constexpr bool LIN = !PAD || ((NS * PS) % 32 == 0) || (NS == 1 && PS == 1 && RAD == 32);
+                constexpr bool LIN = !PAD || ((NS * PS) % 32 == 0) || (NS == 1 && PS == 1 && 32 % RAD == 0);
                 if constexpr (LIN) {
                     cf* wp = lds + lds_phys<PAD>(base * PS + fofs);
 #pragma unroll
@@ -422,9 +444,21 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 }
                 __syncthreads();
             }
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, false, HK>(v, lds, tau, fofs, w + stage_seeds(M, NS, R), hk);
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, false, HK, ORD, PIN, POUT>(v, lds, tau, fofs, w + stage_seeds(M, NS, R, ORD, POUT), hk);
         } else if constexpr (!LAST) {
             tile_sync<WSYNC>();
+            constexpr int NRAD = stage_radix(M, NS * RAD, R, ORD), NNB = R / NRAD;
+            constexpr bool NEXT_PAIRS = POUT && NS * RAD * NRAD == M && NNB > 1;   // the next stage is the last, pair-adjacent
+            if constexpr (NEXT_PAIRS) {
+                // v[q + j NNB] = position (NNB tau + q) + j M/NRAD: NNB consecutive slots per read (M/NRAD is a multiple of 32
+                // slots for row tiles, so the padded map stays linear in j; the pair never straddles a pad slot)
+                static_assert(PS == 1 && (M / NRAD) % 32 == 0 && 32 % NNB == 0, "pair-adjacent last stage: row tiles");
+                const cf* rp = lds + lds_phys<PAD>(NNB * tau + fofs);
+#pragma unroll
+                for (int j = 0; j < NRAD; ++j)
+#pragma unroll
+                    for (int q = 0; q < NNB; ++q) v[q + j * NNB] = rp[lds_lin<PAD>(j * (M / NRAD)) + q];
+            } else {
             constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
             if constexpr (RLIN) {
                 const cf* rp = lds + lds_phys<PAD>(tau * PS + fofs);
@@ -434,8 +468,9 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
 #pragma unroll
                 for (int i = 0; i < R; ++i) v[i] = lds[lds_phys<PAD>((tau + i * MR) * PS + fofs)];
             }
+            }
             tile_sync<WSYNC>();
-            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, WSYNC, HK>(v, lds, tau, fofs, w + stage_seeds(M, NS, R), hk);
+            fft_tile<M, NS * RAD, R, DIR, PS, PAD, XS, WSYNC, HK, ORD, PIN, POUT>(v, lds, tau, fofs, w + stage_seeds(M, NS, R, ORD, POUT), hk);
         }
     }
 }

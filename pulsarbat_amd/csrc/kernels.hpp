@@ -701,6 +701,134 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
         rd = rdn;
     }
 }
+// ---- the same pass with 16-byte accesses ------------------------------------------------------------------------------
+// k_rowp moves its rows with 8 bytes per lane (the tile FFT leaves thread tau with points tau + 512 i).  One persistent
+// 512-thread workgroup per CU streaming 128-KiB rows that way needs 1.05 ms for the pass's 4.3 GB WITHOUT any transform
+// (tools/micro/rowcopy.hip), which is what k_rowp takes; with 16 bytes per lane the same bytes move in 0.82 ms.  Here the
+// forward transform runs its stages as 16, 32, 32 with the two radix-16 butterflies of a thread starting from ADJACENT
+// points (2 tau, 2 tau + 1) + 1024 j, and the inverse transform (32, 32, 16) ends with the same assignment: a row is
+// loaded and stored as 16 x 16 bytes per thread instead of 32 x 8.  Between the two transforms the points sit in the
+// natural distribution tau + 512 i, which is the order of the phase row.  (M = 2^14, float32.)
+// ABL (experiments): 1 = no transforms (memory traffic and the loop only)
+template <int R, int ABL = 0>
+__global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
+    constexpr int M = kTilePoints;
+    static_assert(M == 16384 && R == 32, "k_rowp16: 2^14-point rows, 32 points per thread");
+    constexpr int MR = M / R;
+    constexpr int PSTEP = MR * (int)sizeof(float);
+    constexpr int STEP16 = (M / 16) * (int)sizeof(cf);          // 1024 elements between a thread's 16-byte pairs
+    constexpr int NSF = tw_seeds_or1(M, R, 1, false), NSI = tw_seeds_or1(M, R, 0, true);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    unsigned* slot = reinterpret_cast<unsigned*>(smem + lds_tile_bytes<true>());
+
+    const int tau = threadIdx.x;
+    const int voff16 = tau * 2 * (int)sizeof(cf), pvoff = tau * (int)sizeof(float);
+    const uint32_t npair = (uint32_t)p.nchan * (uint32_t)p.N1;
+    const uint32_t G = gridDim.x;
+
+    cf wf[NSF], wi[NSI];
+    load_tw_seeds<M, 1, R, 1, false>(wf, tau, p.tw16k);
+    load_tw_seeds<M, 1, R, 0, true>(wi, tau, p.tw16k);
+
+    auto row_rsrc = [&](uint32_t u, int pol) {
+        if (u >= npair) return make_rsrc(p.data, 0);
+        const uint32_t chan = u / (uint32_t)p.N1, k1 = u - chan * (uint32_t)p.N1;
+        const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + k1;
+        return make_rsrc(p.data + row * M, (uint32_t)(M * sizeof(cf)));
+    };
+    auto load_pair = [&](rsrc_t r, int j, cf& a, cf& b) {   // points (2 tau, 2 tau + 1) + 1024 j
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff16, j * STEP16, 0);
+        a = make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
+        b = make_cf(__uint_as_float(x.z), __uint_as_float(x.w));
+    };
+    auto store_pair = [&](rsrc_t r, int j, cf a, cf b) {
+        u32x4 x;
+        x.x = __float_as_uint(a.x); x.y = __float_as_uint(a.y); x.z = __float_as_uint(b.x); x.w = __float_as_uint(b.y);
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff16, j * STEP16, 0);
+    };
+
+    uint32_t u = blockIdx.x;
+    if (u >= npair) return;
+    uint32_t unx = u + G;
+    int pol = 0;
+    rsrc_t rd = row_rsrc(u, 0);
+    cf v[R];
+#pragma unroll
+    for (int j = 0; j < R / 2; ++j) load_pair(rd, j, v[2 * j], v[2 * j + 1]);
+    // the first tile's samples are waited for HERE: a wait at the loop header would be the merge of this path (16 loads pending)
+    // and the back edge (only the previous tile's 16 stores pending) -- vmcnt(0), every iteration waiting for its stores' acknowledgements
+    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0): the first tile's samples and the twiddle seeds
+    launder_all(v, std::make_integer_sequence<int, R>{});
+    launder_all(wf, std::make_integer_sequence<int, NSF>{});
+    launder_all(wi, std::make_integer_sequence<int, NSI>{});
+    float ph[R];
+    unsigned fetched = 0;
+
+    while (true) {
+        launder_all(wf, std::make_integer_sequence<int, NSF>{});
+        launder_all(wi, std::make_integer_sequence<int, NSI>{});
+        // the wait for this tile's samples (requested during the previous inverse transform) belongs HERE, in front of the
+        // phase loads of a new pair: left to the first butterfly it lands behind them and waits for them as well
+        launder_all(v, std::make_integer_sequence<int, R>{});
+        if (pol == 0) {
+            uint32_t up = u;
+            if (p.cP > 1) {
+                const uint32_t ch = u / (uint32_t)p.N1, k1d = u - ch * (uint32_t)p.N1;
+                up = ch * (uint32_t)p.N1 + (k1d % (uint32_t)p.cP) * (uint32_t)(p.N1 / p.cP) + k1d / (uint32_t)p.cP;
+            }
+            const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * M, (uint32_t)(M * sizeof(float)));
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));
+        }
+        // forward: 16 (pair-adjacent bases), 32, 32 -> natural distribution tau + 512 i
+        if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true, false, false, NoHook, 1, true, false>(v, lds, tau, 0, wf);
+        if (pol == 0) {   // the index of the pair after next: the atomic's round trip is waited for where the phase values are
+                          // needed anyway (nothing else is in flight here), not at the top of the loop
+            fetched = unx + G;
+            if (tau == 0 && p.counter) fetched = 2 * G + atomicAdd(p.counter, 1u);
+            if (tau == 0) slot[0] = fetched;
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const cf c = make_cf(__builtin_amdgcn_cosf(ph[i]) * p.scale, __builtin_amdgcn_sinf(ph[i]) * p.scale);
+            v[i] = cmul(v[i], c);
+        }
+
+        const bool last_pol = pol == p.npol - 1;
+        const uint32_t un = last_pol ? unx : u;
+        const int poln = last_pol ? 0 : pol + 1;
+        const bool more = un < npair;
+        const rsrc_t rdn = row_rsrc(un, poln);
+        cf nx[R];
+        int cnt = 0;
+        auto hk = [&](auto st, auto q) {
+            if constexpr (std::is_same<decltype(q), tick_tag>::value) {   // the next tile: one 16-byte load per tick
+                __builtin_amdgcn_sched_barrier(0x38E);
+                if (cnt < R / 2) { load_pair(rdn, cnt, nx[2 * cnt], nx[2 * cnt + 1]); ++cnt; }
+                __builtin_amdgcn_sched_barrier(0x38E);
+            }
+        };
+        // inverse: 32, 32, 16 ending on pair-adjacent bases: v[q + 2 u] = X[2 tau + q + 1024 u]
+        if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true, false, false, decltype(hk), 0, false, true>(v, lds, tau, 0, wi, hk);
+        else __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) store_pair(rd, j, v[2 * j], v[2 * j + 1]);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k)
+            if (cnt < R / 2) { load_pair(rdn, cnt, nx[2 * cnt], nx[2 * cnt + 1]); ++cnt; }
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = nx[i];
+        if (last_pol) {
+            u = unx;
+            unx = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);
+        }
+        pol = poln;
+        rd = rdn;
+    }
+}
 #endif  // !PBH_F64
 
 // ---- forward-only row FFT, in place (builds the Bluestein kernel's spectrum in plan order) -------------------

@@ -378,6 +378,12 @@ static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (int64_t)prm.nchan * (prm.N1 / FR);
     if (tiles > row_grid()) tiles = row_grid();
+    // PBH_ROW16=0 keeps the 8-byte-per-lane kernel for 2^14-point rows (A/B runs)
+    static const bool row16 = [] { const char* e = getenv("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
+    static const bool nofft = [] { const char* e = getenv("PBH_ROW16_NOFFT"); return e ? atoi(e) != 0 : false; }();
+    if (row16 && M == kTilePoints)
+        return nofft ? launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16)
+                     : launch_tile_kernel(k_rowp16<PBH_R, 0>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_rowp<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)
