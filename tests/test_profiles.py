@@ -9,11 +9,11 @@ P = os.path.join(ROOT, "profiles")
 
 
 def test_rocprof_agrees_with_bench_line():
-    bench = json.loads(open(os.path.join(P, "r02z_bench.json")).read().strip().splitlines()[-1])
+    bench = json.loads(open(os.path.join(P, "r02z2_bench.json")).read().strip().splitlines()[-1])
     roof = bench["roofline"]
     assert roof["kernel"] == "k_row_fused"
-    rows = list(csv.DictReader(open(os.path.join(P, "r02z_planar5_kernel_stats.csv"))))
-    row = [r for r in rows if "k_rowp<" in r["Name"]]
+    rows = list(csv.DictReader(open(os.path.join(P, "r02z2_planar5_kernel_stats.csv"))))
+    row = [r for r in rows if "k_rowp16<" in r["Name"]]
     assert len(row) == 1
     avg_ms = float(row[0]["AverageNs"]) / 1e6
     assert abs(avg_ms - roof["ms_per_launch"]) / roof["ms_per_launch"] < 0.10
