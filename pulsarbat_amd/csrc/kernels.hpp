@@ -387,7 +387,11 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
     const int tau = tid % MR, f = tid / MR;
     const int voff = (f * M + tau) * (int)sizeof(cf);
     const int cvoff = ((f / p.cdiv) * M + tau) * (int)sizeof(cf);   // chirp row of tile row f
-    const int64_t ntile = (p.nrows + FR - 1) / FR;
+    // tiles of several rows never straddle two series: a series of N1 rows is ceil(N1 / FR) tiles, the last one short when
+    // N1 is not a multiple of FR (odd N1 of the 7-smooth lengths); N1 = 1 (rows = consecutive series) packs FR series per tile
+    const bool by_series = FR > 1 && p.N1 > 1;
+    const int64_t tps = by_series ? (p.N1 + FR - 1) / FR : 1;
+    const int64_t ntile = by_series ? (p.nrows / p.N1) * tps : (p.nrows + FR - 1) / FR;
 
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
@@ -400,12 +404,16 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
             const int64_t chan = pair / p.N1, k1 = pair - chan * p.N1;
             return (chan * p.npol + pol) * (int64_t)p.N1 + k1;
         }
+        if (by_series) return (t / tps) * p.N1 + (t % tps) * FR;
         return t * FR;
     };
+    auto rows_of = [&](int64_t r0) -> int64_t {   // rows of the tile that starts at row r0
+        int64_t left = p.nrows - r0;
+        if (by_series) left = p.N1 - r0 % p.N1;
+        return left < FR ? left : FR;
+    };
     auto data_rsrc = [&](int64_t r0) {
-        const int64_t left = p.nrows - r0;
-        const uint32_t bytes = (uint32_t)((left < FR ? left : FR) * (int64_t)M * sizeof(cf));
-        return make_rsrc(p.data + r0 * M, bytes);
+        return make_rsrc(p.data + r0 * M, (uint32_t)(rows_of(r0) * (int64_t)M * sizeof(cf)));
     };
 
     int64_t t = blockIdx.x;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
         const int k1d = (int)(r0 - srs * p.N1);
         const int k1 = p.cP > 1 ? (k1d % p.cP) * (p.N1 / p.cP) + k1d / p.cP : k1d;
         const rsrc_t rc = make_rsrc(p.chirp + ((srs / p.npol) * p.N1 + k1) * (int64_t)M,
-                                    (uint32_t)(FR * (int64_t)M * sizeof(cf)));
+                                    (uint32_t)((by_series ? rows_of(r0) : FR) * (int64_t)M * sizeof(cf)));
         if constexpr (PF) {
             cf c[R];
             if constexpr (SP == 2) {
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
     const int tau = threadIdx.x % MR, frow = threadIdx.x / MR;
     const int fofs = frow * M;
     const int voff = (fofs + tau) * (int)sizeof(cf), pvoff = (fofs + tau) * (int)sizeof(float);
-    const uint32_t NB = (uint32_t)p.N1 / FR;                  // k1 groups per series
+    const uint32_t NB = ((uint32_t)p.N1 + FR - 1) / FR;       // k1 groups per series (the last one short when FR does not divide N1)
     const uint32_t npair = (uint32_t)p.nchan * NB;
     const uint32_t G = gridDim.x;
 
@@ -628,7 +636,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
         if (u >= npair) return make_rsrc(p.data, 0);
         const uint32_t chan = u / NB, kb = u - chan * NB;
         const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + (int64_t)kb * FR;
-        return make_rsrc(p.data + row * M, (uint32_t)(kTilePoints * sizeof(cf)));
+        const uint32_t rows = (uint32_t)p.N1 - kb * FR < (uint32_t)FR ? (uint32_t)p.N1 - kb * FR : (uint32_t)FR;
+        return make_rsrc(p.data + row * M, (uint32_t)(rows * M * sizeof(cf)));
     };
 
     uint32_t u = blockIdx.x;
@@ -650,7 +659,9 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
                 const uint32_t ch = u / (uint32_t)p.N1, k1d = u - ch * (uint32_t)p.N1;
                 up = ch * (uint32_t)p.N1 + (k1d % (uint32_t)p.cP) * (uint32_t)(p.N1 / p.cP) + k1d / (uint32_t)p.cP;
             }
-            const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * kTilePoints, (uint32_t)(kTilePoints * sizeof(float)));
+            const uint32_t pch = up / NB, pkb = up - pch * NB;   // phase rows of the group: (chan N1 + kb FR) .. + rows
+            const uint32_t prows = (uint32_t)p.N1 - pkb * FR < (uint32_t)FR ? (uint32_t)p.N1 - pkb * FR : (uint32_t)FR;
+            const rsrc_t rp = make_rsrc(p.phase + ((int64_t)pch * p.N1 + (int64_t)pkb * FR) * M, (uint32_t)(prows * M * sizeof(float)));
 #pragma unroll
             for (int i = 0; i < R; ++i)
                 ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));

@@ -56,6 +56,7 @@
 
 #include "aux_kernels.hpp"
 #include "kernels.hpp"
+#include "mixed_kernels.hpp"
 
 using namespace PBH_NS;
 
@@ -117,6 +118,33 @@ static int64_t convolution_length(int64_t x) {
     return best;
 }
 
+// 7-smooth lengths that are neither 2^k nor native m * 2^k: N = P * Q * N2 with N2 = 2^min(k, tile) >= 32 the row length
+// and P, Q <= kMixMaxLen (P = 1 when N / N2 fits one column tile).  PBH_MIXED=0 sends them through the convolution plan.
+static bool is_7smooth(int64_t n) {
+    for (int f : {2, 3, 5, 7}) while (n % f == 0) n /= f;
+    return n == 1;
+}
+static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
+    static const bool on = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) != 0 : true; }();
+    if (!on || n < 64 || is_pow2(n) || !is_7smooth(n)) return false;
+    int k = 0;
+    while (((n >> k) & 1) == 0) ++k;
+    if (k > kTileLog2) k = kTileLog2;
+    if (k < 5) return false;                 // rows shorter than 32 points: a column tile would not hold whole lines
+    const int64_t n1 = n >> k;
+    if (n1 < 2) return false;
+    int64_t q = 0;
+    if (n1 <= kMixMaxLen) q = n1;
+    else
+        for (int64_t d = kMixMaxLen; d >= 2; --d)
+            if (n1 % d == 0 && n1 / d <= kMixMaxLen) { q = d; break; }
+    if (!q) return false;
+    *N2 = 1 << k;
+    *N1 = (int)n1;
+    *P = (int)(n1 / q);
+    return true;
+}
+
 // ---- plan ------------------------------------------------------------------------------------------------
 constexpr size_t kCounterBytes = 4096;   // tile hand-out counters of the persistent kernels, behind the stage twiddle table
 constexpr int kCounters = (int)(kCounterBytes / sizeof(unsigned));
@@ -163,6 +191,16 @@ struct pbh_plan {
     void* stage_out = nullptr;  // device staging for host outputs
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
     int64_t owned_bytes = 0;
+    // 7-smooth lengths (mixed_kernels.hpp): N = N1 * N2, N2 = 2^k rows of the power-of-two engine, N1 = P * Q any 7-smooth
+    // number with P, Q <= kMixMaxLen; both column roles run k_colmix (mixP: the P-point stage, mixQ: the Q-point pass)
+    struct MixTable {
+        int L = 0, nstage = 0;
+        int radix[kMixMaxStages] = {};
+        cf* wl = nullptr;
+        unsigned short* perm = nullptr;
+    };
+    bool mixed = false;
+    MixTable mixP, mixQ;
 };
 
 static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
@@ -177,6 +215,7 @@ static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
 
 static int resolved_variant(const pbh_plan* p) {
     if (p->N1 == 1) return PBH_VARIANT_DIRECT3;  // single tile: no passes to choose
+    if (p->mixed) return PBH_VARIANT_PLANAR5;    // 7-smooth lengths: planar pipeline with mixed-radix column passes
     if (p->P > 1) return PBH_VARIANT_PLANAR5;    // long blocks: only the planar pipeline has the split column pass
     if (p->variant != PBH_VARIANT_AUTO) return p->variant;
     // direct3 touches full 128-B lines only when a 16-column tile spans whole time samples of few
@@ -221,9 +260,11 @@ static int launch_tile_kernel(K kernel, const P& prm, int64_t tiles, int threads
 #ifdef PBH_F64
 #define FOR_ALL_M(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 #define FOR_ROW_M(X) X(1024) X(2048) X(4096) X(8192)
+#define FOR_ROW_SHORT(X) X(32) X(64) X(128) X(256) X(512)
 #else
 #define FOR_ALL_M(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192) X(16384)
 #define FOR_ROW_M(X) X(1024) X(2048) X(4096) X(8192) X(16384)
+#define FOR_ROW_SHORT(X) X(32) X(64) X(128) X(256) X(512)
 #endif
 
 static int row_grid() {
@@ -300,6 +341,7 @@ static int launch_radix(int P, const cf* src, int64_t src_plane, cf* dst, int64_
 static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (prm.nrows + FR - 1) / FR;
+    if (FR > 1 && prm.N1 > 1) tiles = (prm.nrows / prm.N1) * ((prm.N1 + FR - 1) / FR);   // tiles do not straddle series (k_row)
     if (tiles > row_grid()) tiles = row_grid();
 #if defined(PBH_DIAGNOSTIC) && !defined(PBH_F64)  // ablation builds: -DPBH_DIAGNOSTIC, then PBH_ROW_ABL=1|2|3
     static int abl = [] { const char* e = getenv("PBH_ROW_ABL"); return e ? atoi(e) : 0; }();
@@ -354,6 +396,7 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_row<m, PBH_R, true, 0, 2>, q, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)
+        FOR_ROW_SHORT(X)   // rows of the 7-smooth plans whose power-of-two part is small (N = 2^7 5^7: 128-point rows)
 #undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "row pass length " + std::to_string(M));
@@ -372,11 +415,11 @@ static bool row_phase_enabled() {
 // rows of M = N2 points, 2^tile / M of them (consecutive k1 of one series) per tile
 static bool rowp_ok(int N1, int N2) {
     const int FR = kTilePoints / N2;
-    return N2 >= 1024 && N2 <= kTilePoints && FR >= 1 && N1 % FR == 0;
+    return N2 >= 1024 && N2 <= kTilePoints && FR >= 1 && N1 >= 1;   // (a series whose N1 is not a multiple of FR ends in a short tile)
 }
 static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     const int FR = kTilePoints / M;
-    int64_t tiles = (int64_t)prm.nchan * (prm.N1 / FR);
+    int64_t tiles = (int64_t)prm.nchan * ((prm.N1 + FR - 1) / FR);
     if (tiles > row_grid()) tiles = row_grid();
     // PBH_ROW16=0 keeps the 8-byte-per-lane kernel for 2^14-point rows (A/B runs)
     static const bool row16 = [] { const char* e = getenv("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
@@ -614,6 +657,16 @@ struct DetectTail {
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 
+template <int DIR>
+static int launch_colmix(const MixParams& prm, hipStream_t st) {
+    constexpr int COLS = 128 / (int)sizeof(cf);
+    const size_t lds = (size_t)prm.L * COLS * sizeof(cf) + (size_t)prm.L * sizeof(cf) + (size_t)prm.L * sizeof(unsigned short) + 16;
+    int64_t tiles = (int64_t)prm.S * prm.nblock * prm.ncolgrp;
+    const int64_t per_cu = lds <= 80 * 1024 ? 2 : 1;
+    if (tiles > 256 * per_cu * 2) tiles = 256 * per_cu * 2;   // persistent: a few tiles per workgroup slot
+    return launch_tile_kernel(k_colmix<DIR>, prm, tiles, 512, st, (int)lds);
+}
+
 // device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major
 struct IoLayout {
     int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
@@ -732,6 +785,104 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         SmallParams sp{in, out, p->chirp, p->tw16k, S, p->npol, p->start, p->stop, -1, (real)1};
         const int M = (int)p->N;
         steps.push_back({"k_small", [=](hipStream_t st) { return launch_small(M, sp, st); }});
+        return steps;
+    }
+    if (p->mixed) {
+        // 7-smooth length: de-interleave, [P-point stage], Q-point column pass, fused rows, and back (mixed_kernels.hpp)
+        const int64_t N = p->N, start = p->start, stop = p->stop;
+        const int N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
+        constexpr int COLS = 128 / (int)sizeof(cf);
+        cf* work = p->work;
+        BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
+        tw.nmod = N;
+        const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
+        const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
+        if (!in_sm) {
+            const double* mft = io.mix_ft;
+            steps.push_back({"k_deinterleave", [=](hipStream_t st) {
+                return launch_deinterleave(in, work, N, S, nvalid, st, 0, mft);
+            }});
+        }
+        const pbh_plan::MixTable tp = p->mixP, tq = p->mixQ;
+        auto role_a = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
+            MixParams m{};
+            m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
+            m.S = S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) / COLS;
+            m.xdiv = N2; m.ystep = 1; m.nmod = N1; m.mult = N2; m.y0mul = 0;
+            m.tw = tw; m.nstage = tp.nstage;
+            for (int j = 0; j < tp.nstage; ++j) m.radix[j] = tp.radix[j];
+            m.wl = tp.wl; m.perm = tp.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+            return m;
+        };
+        auto role_b = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
+            MixParams m{};
+            m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
+            m.S = S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 / COLS;
+            m.xdiv = 1; m.ystep = P; m.nmod = N; m.mult = 1; m.y0mul = 1;
+            m.tw = tw; m.nstage = tq.nstage;
+            for (int j = 0; j < tq.nstage; ++j) m.radix[j] = tq.radix[j];
+            m.wl = tq.wl; m.perm = tq.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+            return m;
+        };
+        const cf* src = in_sm ? in : work;          // a series-major input is read by the first column pass, out of place
+        int64_t splane = in_sm ? io.in_pitch : N;
+        if (P > 1) {
+            const MixParams a = role_a(src, splane, work, N, 0, N, 0);
+            steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_colmix<-1>(a, st); }});
+            src = work;
+            splane = N;
+        }
+        {
+            const MixParams b = role_b(src, splane, work, N, 0, N, 0);
+            steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colmix<-1>(b, st); }});
+        }
+        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+        RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, 0, ctr + 2};
+#ifndef PBH_F64
+        if (p->has_phase && row_phase_enabled()) {
+            RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)N), ctr + 2};
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
+        } else
+#endif
+        steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
+        // the last inverse pass is the one whose rows are times: it crops, and writes a series-major output itself
+        const bool direct_out = out_sm && !tail.out;
+        cf* dst = direct_out ? out : work;
+        const int64_t dplane = direct_out ? io.out_pitch : N, dshift = direct_out ? start : 0;
+        {
+            const MixParams b = P > 1 ? role_b(work, N, work, N, 0, N, 0) : role_b(work, N, dst, dplane, start, stop, dshift);
+            steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colmix<+1>(b, st); }});
+        }
+        if (P > 1) {
+            const MixParams a = role_a(work, N, dst, dplane, start, stop, dshift);
+            steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
+        }
+        if (tail.out) {
+            const int nchan = p->nchan, npol = p->npol;
+            const int64_t nout = (stop - start) / tail.nscrunch;
+            steps.push_back({"k_detect_planar", [=](hipStream_t st) {
+                if (nout <= 0) return (int)PBH_OK;
+                hipLaunchKernelGGL(k_detect_planar, dim3((unsigned)((nout + 3) / 4), (unsigned)nchan), dim3(256), 0, st,
+                                   (const cf*)work, tail.out, N, start, nout, nchan, npol, tail.mode, tail.nscrunch);
+                HIPCHECK(hipGetLastError());
+                return (int)PBH_OK;
+            }});
+        } else if (!out_sm) {
+            const int64_t orow = io.out_row_elems;
+            const auto pp = io.part_ptr;
+            const auto pr = io.part_row;
+            steps.push_back({"k_reinterleave", [=](hipStream_t st) {
+                return launch_reinterleave_parts(work, out, start, stop, S, N, st, orow, pp, pr);
+            }});
+        }
+        if (!steps.empty()) {
+            unsigned* ctr0 = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+            auto first = steps[0].launch;
+            steps[0].launch = [=](hipStream_t st) {
+                HIPCHECK(hipMemsetAsync(ctr0, 0, kCounterBytes, st));
+                return first(st);
+            };
+        }
         return steps;
     }
     const int variant = resolved_variant(p);
@@ -1245,6 +1396,42 @@ static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
     return PBH_OK;
 }
 
+// stage radices, W_L table and output permutation of a mixed-radix column transform of length L (mixed_kernels.hpp)
+static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t) {
+    t->L = L;
+    t->nstage = 0;
+    int left = L;
+    for (int r : {7, 5, 3}) while (left % r == 0) { if (t->nstage >= kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "too many stages"); t->radix[t->nstage++] = r; left /= r; }
+    while (left % 8 == 0) { t->radix[t->nstage++] = 8; left /= 8; }
+    while (left % 4 == 0) { t->radix[t->nstage++] = 4; left /= 4; }
+    while (left % 2 == 0) { t->radix[t->nstage++] = 2; left /= 2; }
+    if (left != 1 || t->nstage > kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "length is not 7-smooth");
+    std::vector<cf> w(L);
+    for (int i = 0; i < L; ++i) {
+        const double a = -2.0 * M_PI * (double)i / (double)L;
+        w[i] = make_cf((real)cos(a), (real)sin(a));
+    }
+    // X[k], k = u1 + r1 (u2 + r2 (u3 + ...)), ends at position u1 L/r1 + u2 L/(r1 r2) + ...
+    std::vector<unsigned short> perm(L);
+    for (int k = 0; k < L; ++k) {
+        int rest = k, m = L, pos = 0;
+        for (int j = 0; j < t->nstage; ++j) {
+            const int r = t->radix[j];
+            m /= r;
+            pos += (rest % r) * m;
+            rest /= r;
+        }
+        perm[k] = (unsigned short)pos;
+    }
+    int rc;
+    if ((rc = dev_alloc(p, (void**)&t->wl, sizeof(cf) * L)) != PBH_OK) return rc;
+    if ((rc = dev_alloc(p, (void**)&t->perm, sizeof(unsigned short) * L)) != PBH_OK) return rc;
+    if (hipMemcpy(t->wl, w.data(), sizeof(cf) * L, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t->perm, perm.data(), sizeof(unsigned short) * L, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(PBH_ERR_HIP, "hipMemcpy(mixed-radix tables) failed");
+    return PBH_OK;
+}
+
 static int launch_rowfft(int M, cf* data, const cf* tw, int64_t nrows, hipStream_t st) {
     const int FR = kTilePoints / M;
     const int64_t tiles = (nrows + FR - 1) / FR;
@@ -1453,11 +1640,18 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     p->start = crop_start;
     p->stop = crop_stop < crop_start ? crop_start : crop_stop;  // empty result if the crop is negative
     const int n = ilog2(nsample);
+    int mN1 = 0, mN2 = 0, mP = 0;
     if (odd_m) {
         // the odd factor is the radix-P stage of the split column transform: N1 = m * Q rows, Q a power of two
         p->N2 = kTilePoints;
         p->N1 = (int)(nsample / kTilePoints);
         p->P = odd_m;
+    } else if (!pow2 && plain_fft != 1 && mixed_geometry(nsample, &mN1, &mN2, &mP)) {
+        // 7-smooth: both column roles are mixed-radix transforms in LDS (k_colmix), the rows stay with the 2^k engine
+        p->N1 = mN1;
+        p->N2 = mN2;
+        p->P = mP;
+        p->mixed = true;
     } else if (!pow2) {
         p->N1 = 1;  // natural-order chirp H/N; the transforms run in a native-length convolution plan
         p->N2 = (int)nsample;
@@ -1471,7 +1665,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = 1 << l2;
         p->N1 = (int)(nsample >> l2);
     }
-    if (p->N1 > 1 && !odd_m) {
+    if (p->N1 > 1 && !odd_m && !p->mixed) {
         // column tiles whose rows are narrower than a 128-byte line are avoided by splitting N1 = P * Q with
         // Q rows per tile such that a tile row is one line; PBH_QMAX overrides Q (tests exercise the split at
         // small sizes)
@@ -1542,6 +1736,10 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     if (p->bsL) {
         if ((rc = plain_fft ? setup_bluestein(p) : setup_circular(p)) != PBH_OK) return bail(rc);
     }
+    if (p->mixed) {
+        if (p->P > 1 && (rc = build_mix_table(p, p->P, &p->mixP)) != PBH_OK) return bail(rc);
+        if ((rc = build_mix_table(p, p->N1 / p->P, &p->mixQ)) != PBH_OK) return bail(rc);
+    }
     *out = p;
     return PBH_OK;
 }
@@ -1553,7 +1751,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) hipFree(p->cf_in);
     void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
-                    p->bs_b, p->bs_a, p->bs_conv};
+                    p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete p;
@@ -1591,7 +1789,7 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
     info->variant = resolved_variant(p);
     // (long blocks: +2 for the stand-alone radix-P stage unless it is folded into the layout passes)
     info->nkernel = p->N1 == 1 ? ((p->work && single_planar_ok(p)) ? 3 : 1) : (info->variant == PBH_VARIANT_PLANAR5 ? 5 : 3) +
-                                         ((p->P > 1 && !radix_layout_ok(p->S, p->P, p->N, p->N2)) ? 2 : 0);
+                                         ((p->P > 1 && (p->mixed || !radix_layout_ok(p->S, p->P, p->N, p->N2))) ? 2 : 0);
     if (p->bsL && p->cfilt) {
         pbh_plan_info_t sub;
         pbh_plan_info(p->cfilt, &sub);
@@ -2026,7 +2224,7 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     HIPCHECK(hipSetDevice(p->device));
     if (nout <= 0) return PBH_OK;
     const bool any_sm = in_layout == PBH_LAYOUT_SERIES_MAJOR || out_layout == PBH_LAYOUT_SERIES_MAJOR;
-    if (any_sm && (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
+    if (any_sm && !p->mixed && (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                    p->N >= (1LL << 31)))
         return fail(PBH_ERR_UNSUPPORTED, "series-major I/O needs a multi-pass power-of-two plan (nsample > one tile)");
     IoLayout io;
@@ -2061,7 +2259,7 @@ int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nc
     if (nout <= 0) return PBH_OK;
     const int E = p->npol, M = nperseg;
     const int64_t Sin = (int64_t)nchan_in * E;
-    const bool multipass = !(p->bsL || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+    const bool multipass = !(p->bsL || p->mixed || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
                              p->N >= (1LL << 31));
     if (out_layout == PBH_LAYOUT_SERIES_MAJOR && !multipass)
         return fail(PBH_ERR_UNSUPPORTED, "series-major output needs a multi-pass power-of-two plan (nsample > one tile)");
@@ -2131,7 +2329,7 @@ static int launch_place(hipStream_t st, const cf* src, int64_t ipitch, cf* dst, 
 // true when the plan's last kernel can write pitched rows itself (launch_reinterleave's row transposes / generic kernel)
 static bool slice_fast_ok(const pbh_plan* p) {
     if (p->bsL || p->N1 == 1 || resolved_variant(p) != PBH_VARIANT_PLANAR5) return false;
-    if (p->P > 1 && radix_layout_ok(p->S, p->P, p->N, p->N2)) return false;   // the inverse radix stage rides in the layout pass
+    if (p->P > 1 && !p->mixed && radix_layout_ok(p->S, p->P, p->N, p->N2)) return false;   // the inverse radix stage rides in the layout pass
     return blk_series(p->S, p->N) == 0;
 }
 
@@ -2354,7 +2552,7 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
     if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
     if (in_layout == PBH_LAYOUT_SERIES_MAJOR) {
         if (in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
-        if (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
+        if ((!p->mixed && (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0)) ||
             p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
             p->nchan > 65535)
             return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan and nscrunch % 64 == 0");
@@ -2907,7 +3105,7 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
         cap = spans[(size_t)k].len > cap ? spans[(size_t)k].len : cap;
     }
     HIPCHECK(hipSetDevice(p->device));
-    const bool sm = !(p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
+    const bool sm = !(p->bsL || p->mixed || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                       p->N >= (1LL << 31)) && p->S > 1;
     const size_t row = sizeof(cf) * (size_t)p->S;
     const size_t out_bytes = row * (size_t)hop, host_out_bytes = out_bytes * (size_t)nchunk;

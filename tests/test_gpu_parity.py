@@ -965,3 +965,60 @@ def test_channelised_block_beyond_2gib():
         ref = scipy.fft.ifft(scipy.fft.fft(xs, axis=0) * chirp, axis=0)[start:stop]
         got = y.data.tensor[:, c, :].cpu().numpy()
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < RTOL_L2
+
+
+# ---- 7-smooth lengths: what the reference's fast_len / next_fast_len / prev_fast_len hand out --------------------------
+# (reference pulsarbat/utils.py:68-130, transforms.py:364-382).  N = P * Q * 2^k runs the planar pipeline with mixed-radix
+# column passes (k_colmix); pbh_plan_info reports the geometry, so a silent detour through the padded convolution fails.
+SMOOTH = [
+    (288, 9, 32),             # 2^5 3^2: Q = 9, rows of 32 points (512 rows per tile, 9 per series: ragged row tiles)
+    (20000, 625, 32),         # 2^5 5^4
+    (64800, 2025, 32),        # 2^5 3^4 5^2: P = 3, Q = 675
+    (400000, 3125, 128),      # 2^7 5^5: P = 5, Q = 625
+    (107520, 105, 1024),      # 2^10 3 5 7
+    (294912, 18, 16384),      # 2^15 3^2: Q = 18 (radices 3, 3, 2)
+    (1000000, 15625, 64),     # 10^6 = 2^6 5^6: P = 25, Q = 625
+    (735 * 2048, 735, 2048),  # 2^11 3 5 7^2
+    (27 << 16, 108, 16384),   # 2^16 3^3: N1 = 108 keeps a factor 4 (radices 3, 3, 3, 4)
+]
+
+
+@pytest.mark.parametrize("n,n1,n2", SMOOTH)
+@pytest.mark.parametrize("tail", [(1,), (3, 2), (8, 2)])
+def test_7smooth_lengths(n, n1, n2, tail):
+    from pulsarbat_amd import _hip
+    info = _hip.Plan(n, 1, 1, 0, n, device=0).info
+    assert (info["n1"], info["n2"]) == (n1, n2), info
+    if n * int(np.prod(tail)) > 1 << 25:
+        pytest.skip("oracle time")
+    for device in (False, True):
+        check((n,) + tail, 3.0, 1e6, 1e9, seed=n % 97, device=device)
+
+
+def test_7smooth_detect_series_major_and_user_chirp():
+    n, tail = 107520, (4, 2)
+    x = orc.synthetic_block((n,) + tail, 5)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    # fused detection tail
+    d, s0 = pb.dedisperse_detect(z, pb.DM(4.0), mode="I", nscrunch=64)
+    yr, start, stop = orc.coherent_dedispersion(x, 4.0, 1e6, 1e9)
+    want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0], 64)
+    assert s0 == start and np.allclose(np.asarray(d), want, rtol=2e-5)
+    zs0 = type(z).like(z, z.data.to_series_major())
+    d2, _ = pb.dedisperse_detect(zs0, pb.DM(4.0), mode="I", nscrunch=64)
+    assert np.allclose(np.asarray(d2), want, rtol=2e-5)
+    # series-major arrays at both ends
+    zs = type(z).like(z, z.data.to_series_major())
+    ys = pb.coherent_dedispersion(zs, pb.DM(4.0))
+    assert series_errors(np.asarray(ys), yr)[0] < RTOL_L2
+    # a user chirp goes through the plan-order upload
+    c = np.exp(2j * np.pi * np.random.default_rng(0).random((n, tail[0]))).astype(np.complex64)
+    yc = pb.coherent_dedispersion(z, pb.DM(4.0), chirp=c)
+    import scipy.fft
+    ref = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * c[:, :, None], axis=0)[start:stop]
+    assert series_errors(np.asarray(yc), ref)[0] < RTOL_L2
+
+
+@pytest.mark.parametrize("n", [20000, 400000])
+def test_7smooth_c128(n):
+    check128((n, 2, 2), 3.0)
