@@ -12,7 +12,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpbhip.so")
 SOURCES = ["pbhip.hip", "pbhip_api.cpp"]
-HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp",
+HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", "mixed_kernels.hpp",
            os.path.join("..", "..", "include", "pbhip.h")]
 ARCH = "gfx950"
 

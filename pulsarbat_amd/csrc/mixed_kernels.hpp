@@ -32,7 +32,8 @@ struct MixParams {
     int64_t rstride;    // elements between consecutive rows
     int nblock;         // row blocks per series (role B: P blocks of Q rows), block c at c * bstride
     int64_t bstride;
-    int64_t ncolgrp;    // COLS-column groups per block
+    int64_t ncolgrp;    // column groups (W columns each) per block
+    int wlog2;          // W = 2^wlog2 columns per tile: whole 128-byte lines, L * W <= 2^14 points
     // twiddle exponent of (row k, column position x): ((x / xdiv) * (c * y0mul + ystep * k) % nmod) * mult, looked up in tw
     int64_t xdiv, ystep, nmod, mult;
     int y0mul;
@@ -42,19 +43,22 @@ struct MixParams {
     const cf* wl;                  // W_L^p = exp(-2 pi i p / L), p < L
     const unsigned short* perm;    // natural row k sits at LDS row perm[k] after the stages
     int64_t keep0, keep1, st_shift;   // only element indices in [keep0, keep1) are stored (crop of the last inverse pass)
+    unsigned* counter;  // tile hand-out (zeroed before the launch): tiles beyond a workgroup's first two come in launch-wide order,
+                        // so the tiles in flight across the chip stay a tight window of neighbouring column groups (k_colq)
 };
 
 template <int R, int DIR>
-__device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, int cols, int tid, int nthreads) {
+__device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, int wlog2, int tid, int nthreads) {
     const int m = Lj / R, tws = L / Lj;
-    const int nbf = (L / R) * cols;
+    const int nbf = (L / R) << wlog2;
     for (int b = tid; b < nbf; b += nthreads) {
-        const int col = b % cols, q = b / cols;
+        const int col = b & ((1 << wlog2) - 1), q = b >> wlog2;
         const int blk = q / m, i = q - blk * m;
-        cf* base = lds + (blk * Lj + i) * cols + col;
+        cf* base = lds + (((blk * Lj + i)) << wlog2) + col;
+        const int es = m << wlog2;
         cf v[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = base[u * m * cols];
+        for (int u = 0; u < R; ++u) v[u] = base[u * es];
         Dft<R, DIR>::run(v);
         if (m > 1) {
 #pragma unroll
@@ -64,112 +68,152 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < R; ++u) base[u * m * cols] = v[u];
+        for (int u = 0; u < R; ++u) base[u * es] = v[u];
     }
 }
 
+// Two workgroups per CU: a tile is at most 64 KiB of LDS (L * W <= 8192 complex64 points) and the kernel stays within 128
+// VGPRs, so one workgroup's loads and stores overlap the other's stages -- the write path alone needs ~7 us for a tile, as
+// long as its stages take (a single workgroup per CU with 128-KiB tiles and deferred stores measured 1.5x slower).
+constexpr int kMixTileBytes = 65536;
 template <int DIR>
-__global__ __launch_bounds__(512) void k_colmix(MixParams p) {
-    constexpr int COLS = 128 / (int)sizeof(cf);
-    constexpr int NT = 512, RL = NT / COLS;          // RL rows in flight per pass over the tile
-    constexpr int NI = kMixMaxLen / RL;              // rows per thread at the longest length
+__global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
+    constexpr int NT = 512;
+    constexpr int NI = kMixTileBytes / (int)sizeof(cf) / NT;   // rows per thread at most
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
-    cf* wl = lds + (size_t)p.L * COLS;
-    unsigned short* perm = reinterpret_cast<unsigned short*>(wl + p.L);
+    const int L = p.L, W = 1 << p.wlog2;             // W columns per tile (whole 64- or 128-byte pieces), a power of two <= 512
+    cf* wl = lds + (size_t)L * W;
+    unsigned short* perm = reinterpret_cast<unsigned short*>(wl + L);
 
-    const int tid = threadIdx.x, f = tid % COLS, tau = tid / COLS;
-    const int L = p.L;
+    const int tid = threadIdx.x, f = tid & (W - 1), tau = tid >> p.wlog2;
+    const int RL = NT >> p.wlog2;                    // rows in flight per sweep over the tile
     for (int k = tid; k < L; k += NT) {
         wl[k] = p.wl[k];
         perm[k] = p.perm[k];
     }
+    // (the stage radices through LDS: indexing the by-value parameter array with the stage counter would put it in scratch)
+    int* srad = reinterpret_cast<int*>(smem + (((size_t)L * W + L) * sizeof(cf) + (size_t)L * sizeof(unsigned short) + 15) / 16 * 16);
+    if (tid < kMixMaxStages) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < kMixMaxStages; ++j) r = (tid == j) ? p.radix[j] : r;
+        srad[tid] = r;
+    }
     const int64_t ntile = (int64_t)p.S * p.nblock * p.ncolgrp;
-    auto tile_base = [&](int64_t T, int64_t& s, int& c, int64_t& x) -> int64_t {
+    // tile T = (series s, row block c, column group g), g fastest; its first element is (time) index c * bstride + g * W
+    auto tile_origin = [&](int64_t T, int64_t& s, int& c, int64_t& x0) -> int64_t {
         const int64_t g = T % p.ncolgrp, rest = T / p.ncolgrp;
         c = (int)(rest % p.nblock);
         s = rest / p.nblock;
-        x = g * COLS + f;
-        return (int64_t)c * p.bstride + x;    // element index (time) of row 0 of this thread's column
+        x0 = g * W;
+        return (int64_t)c * p.bstride + x0;
     };
+    // Buffer descriptors bound a tile to its L rows: the rows a thread's last sweep reaches beyond them load zeros and drop
+    // their stores without a branch (tile extent < 2^31 bytes: rows are at most N / 2 elements apart and N <= 2^27).
+    const uint32_t tile_bytes = (uint32_t)(((int64_t)(L - 1) * p.rstride + W) * (int64_t)sizeof(cf));
+    const int voff = (int)(((int64_t)tau * p.rstride + f) * (int64_t)sizeof(cf));
+    const int sweep = (int)((int64_t)RL * p.rstride * (int64_t)sizeof(cf));   // bytes between a thread's consecutive rows
+    const int ni = (L + RL - 1) / RL;               // sweeps over the tile (uniform)
+    const int64_t tstep = (int64_t)RL * p.rstride;
 
     int64_t T = blockIdx.x;
     if (T >= ntile) return;
+    int64_t Tn = T + gridDim.x;
+    unsigned* slot = reinterpret_cast<unsigned*>(srad + kMixMaxStages);
     cf v[NI];
     {
-        int64_t s, x; int c;
-        const int64_t e0 = tile_base(T, s, c, x);
-        const cf* src = p.ld + s * p.ld_plane + e0;
+        int64_t s, x0; int c;
+        const int64_t e0 = tile_origin(T, s, c, x0);
+        const rsrc_t rd = make_rsrc(p.ld + s * p.ld_plane + e0, tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int k = tau + RL * i;
-            if (k < L) v[i] = src[(int64_t)k * p.rstride];
-        }
+        for (int i = 0; i < NI; ++i)
+            if (i < ni) v[i] = buf_load(rd, voff, i * sweep);
     }
     while (true) {
-        int64_t s, x; int c;
-        const int64_t e0 = tile_base(T, s, c, x);
+        int64_t s, x0; int c;
+        const int64_t e0 = tile_origin(T, s, c, x0);
         // inter-pass twiddle of this thread's rows tau + RL i: z_i = zb * zs^i (float64 recurrence)
-        const int64_t xx = x / p.xdiv, y0 = (int64_t)c * p.y0mul;
+        const int64_t xx = (x0 + f) / p.xdiv, y0 = (int64_t)c * p.y0mul;
         const double2 zb = big_tw(p.tw, ((xx * (y0 + p.ystep * tau)) % p.nmod) * p.mult);
         const double2 zs = big_tw(p.tw, ((xx * ((p.ystep * RL) % p.nmod)) % p.nmod) * p.mult);
         {
             double2 z = zb;
+            cf* dl = lds + tau * W + f;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int k = tau + RL * i;
-                if (k < L) {
+                if (i < ni) {
                     cf a = v[i];
-                    if (DIR > 0) a = cmul(a, make_cf((real)z.x, (real)-z.y));
-                    lds[k * COLS + f] = a;
+                    if (DIR > 0) {
+                        a = cmul(a, make_cf((real)z.x, (real)-z.y));
+                        z = zmul(z, zs);
+                    }
+                    if (tau + RL * i < L) dl[i * RL * W] = a;
                 }
-                if (DIR > 0) z = zmul(z, zs);
             }
         }
-        const int64_t Tn = T + gridDim.x;
+        unsigned fetched = (unsigned)(Tn + gridDim.x);   // the tile after next: requested now, parked in LDS after the stages
+        if (tid == 0 && p.counter) fetched = 2 * gridDim.x + atomicAdd(p.counter, 1u);
         if (Tn < ntile) {   // the next tile's samples travel while this one is transformed
             int64_t s2, x2; int c2;
-            const int64_t e2 = tile_base(Tn, s2, c2, x2);
-            const cf* src = p.ld + s2 * p.ld_plane + e2;
+            const int64_t e2 = tile_origin(Tn, s2, c2, x2);
+            const rsrc_t rd = make_rsrc(p.ld + s2 * p.ld_plane + e2, tile_bytes);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int k = tau + RL * i;
-                if (k < L) v[i] = src[(int64_t)k * p.rstride];
-            }
+            for (int i = 0; i < NI; ++i)
+                if (i < ni) v[i] = buf_load(rd, voff, i * sweep);
         }
         __syncthreads();
         int Lj = L;
         for (int j = 0; j < p.nstage; ++j) {
-            const int r = p.radix[j];
+            const int r = srad[j];
             switch (r) {
-                case 2: mix_stage<2, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
-                case 3: mix_stage<3, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
-                case 4: mix_stage<4, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
-                case 5: mix_stage<5, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
-                case 7: mix_stage<7, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
-                default: mix_stage<8, DIR>(lds, wl, L, Lj, COLS, tid, NT); break;
+                case 2: mix_stage<2, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 3: mix_stage<3, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 4: mix_stage<4, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 5: mix_stage<5, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 7: mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                default: mix_stage<8, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
             }
             Lj /= r;
             __syncthreads();
         }
         {
-            cf* dst = p.st + s * p.st_plane - p.st_shift;
+            // stores: element (time) index t = e0 + f + k rstride goes to st[t - st_shift] when keep0 <= t < keep1
+            const rsrc_t ro = make_rsrc(p.st + s * p.st_plane + e0 - p.st_shift, tile_bytes);
+            const int64_t ot0 = e0 + f + (int64_t)tau * p.rstride;
             double2 z = zb;
+            constexpr int CH = NI < 8 ? NI : 8;   // a chunk of rows at a time: permutation entries, then the values, then the stores
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int k = tau + RL * i;
-                if (k < L) {
-                    cf a = lds[(int)perm[k] * COLS + f];
-                    if (DIR < 0) a = cmul(a, make_cf((real)z.x, (real)z.y));
-                    const int64_t t = e0 + (int64_t)k * p.rstride;
-                    if (t >= p.keep0 && t < p.keep1) dst[t] = a;
+            for (int i0 = 0; i0 < NI; i0 += CH) {
+                if (i0 < ni) {
+                    int pk[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const int k = tau + RL * (i0 + i);
+                        pk[i] = ((int)perm[k < L ? k : L - 1] << p.wlog2) + f;
+                    }
+                    cf a[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) a[i] = lds[pk[i]];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        cf o = a[i];
+                        if (DIR < 0) {
+                            o = cmul(o, make_cf((real)z.x, (real)z.y));
+                            z = zmul(z, zs);
+                        }
+                        const int64_t t = ot0 + (i0 + i) * tstep;
+                        buf_store(ro, (t >= p.keep0 && t < p.keep1) ? voff : (int)0x80000000, (i0 + i) * sweep, o);   // out of range = dropped
+                    }
                 }
-                if (DIR < 0) z = zmul(z, zs);
             }
         }
         if (Tn >= ntile) break;
-        T = Tn;
+        if (tid == 0) slot[0] = fetched;
         __syncthreads();   // every read of the tile is done before the next one is written over it
+        T = Tn;
+        Tn = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)slot[0]);
+        __syncthreads();   // ... and everyone has the slot before thread 0 writes it again
     }
 }
 

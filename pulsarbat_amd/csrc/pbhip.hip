@@ -125,8 +125,10 @@ static bool is_7smooth(int64_t n) {
     return n == 1;
 }
 static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
-    static const bool on = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) != 0 : true; }();
-    if (!on || n < 64 || is_pow2(n) || !is_7smooth(n)) return false;
+    // PBH_MIXED: 0 = off, 1 (default) = lengths whose N1 fits one column pass (P = 1: 5 passes, 1.3x the rate of the padded
+    // convolution), 2 = two-level lengths as well (7 passes: correct, tested, but not yet faster than the convolution plan)
+    static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 1; }();
+    if (!mode || n < 64 || is_pow2(n) || !is_7smooth(n)) return false;
     int k = 0;
     while (((n >> k) & 1) == 0) ++k;
     if (k > kTileLog2) k = kTileLog2;
@@ -139,6 +141,7 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
         for (int64_t d = kMixMaxLen; d >= 2; --d)
             if (n1 % d == 0 && n1 / d <= kMixMaxLen) { q = d; break; }
     if (!q) return false;
+    if (mode < 2 && n1 / q > 1) return false;
     *N2 = 1 << k;
     *N1 = (int)n1;
     *P = (int)(n1 / q);
@@ -657,14 +660,24 @@ struct DetectTail {
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 
+// columns per k_colmix tile: a power of two, as many as keep L rows within the 64-KiB tile (short transforms get wide
+// tiles: a 25-point stage works on 25 x 256 points per tile); whole 128-byte lines up to L = 512, 64-byte pieces beyond
+static int mix_wlog2(int L, int N2) {
+    const int budget = kMixTileBytes / (int)sizeof(cf);
+    int w = 64 / (int)sizeof(cf);
+    while (2 * w * L <= budget && 2 * w <= 512 && 2 * w <= N2) w *= 2;
+    return ilog2(w);
+}
 template <int DIR>
 static int launch_colmix(const MixParams& prm, hipStream_t st) {
-    constexpr int COLS = 128 / (int)sizeof(cf);
-    const size_t lds = (size_t)prm.L * COLS * sizeof(cf) + (size_t)prm.L * sizeof(cf) + (size_t)prm.L * sizeof(unsigned short) + 16;
+    static const bool nostage = [] { const char* e = getenv("PBH_MIX_NOSTAGE"); return e ? atoi(e) != 0 : false; }();   // (timing runs)
+    MixParams q = prm;
+    if (nostage) q.nstage = 0;
+    const size_t lds = ((size_t)prm.L << prm.wlog2) * sizeof(cf) + (size_t)prm.L * sizeof(cf) + (size_t)prm.L * sizeof(unsigned short) + 16 +
+                       kMixMaxStages * sizeof(int) + 16;
     int64_t tiles = (int64_t)prm.S * prm.nblock * prm.ncolgrp;
-    const int64_t per_cu = lds <= 80 * 1024 ? 2 : 1;
-    if (tiles > 256 * per_cu * 2) tiles = 256 * per_cu * 2;   // persistent: a few tiles per workgroup slot
-    return launch_tile_kernel(k_colmix<DIR>, prm, tiles, 512, st, (int)lds);
+    if (tiles > 512) tiles = 512;   // persistent: two workgroups per CU
+    return launch_tile_kernel(k_colmix<DIR>, q, tiles, 512, st, (int)lds);
 }
 
 // device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major
@@ -791,7 +804,6 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         // 7-smooth length: de-interleave, [P-point stage], Q-point column pass, fused rows, and back (mixed_kernels.hpp)
         const int64_t N = p->N, start = p->start, stop = p->stop;
         const int N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
-        constexpr int COLS = 128 / (int)sizeof(cf);
         cf* work = p->work;
         BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
         tw.nmod = N;
@@ -807,36 +819,42 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         auto role_a = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
             MixParams m{};
             m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
-            m.S = S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) / COLS;
+            m.wlog2 = mix_wlog2(P, N2);
+            m.S = S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) >> m.wlog2;
             m.xdiv = N2; m.ystep = 1; m.nmod = N1; m.mult = N2; m.y0mul = 0;
             m.tw = tw; m.nstage = tp.nstage;
             for (int j = 0; j < tp.nstage; ++j) m.radix[j] = tp.radix[j];
             m.wl = tp.wl; m.perm = tp.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+            m.counter = nullptr;
             return m;
         };
         auto role_b = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
             MixParams m{};
             m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
-            m.S = S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 / COLS;
+            m.wlog2 = mix_wlog2(Q, N2);
+            m.S = S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 >> m.wlog2;
             m.xdiv = 1; m.ystep = P; m.nmod = N; m.mult = 1; m.y0mul = 1;
             m.tw = tw; m.nstage = tq.nstage;
             for (int j = 0; j < tq.nstage; ++j) m.radix[j] = tq.radix[j];
             m.wl = tq.wl; m.perm = tq.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+            m.counter = nullptr;
             return m;
         };
         const cf* src = in_sm ? in : work;          // a series-major input is read by the first column pass, out of place
         int64_t splane = in_sm ? io.in_pitch : N;
+        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);   // tile counters: 2 = rows, 3..6 = the column passes
         if (P > 1) {
-            const MixParams a = role_a(src, splane, work, N, 0, N, 0);
+            MixParams a = role_a(src, splane, work, N, 0, N, 0);
+            a.counter = ctr + 3;
             steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_colmix<-1>(a, st); }});
             src = work;
             splane = N;
         }
         {
-            const MixParams b = role_b(src, splane, work, N, 0, N, 0);
+            MixParams b = role_b(src, splane, work, N, 0, N, 0);
+            b.counter = ctr + 4;
             steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colmix<-1>(b, st); }});
         }
-        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, 0, ctr + 2};
 #ifndef PBH_F64
         if (p->has_phase && row_phase_enabled()) {
@@ -850,11 +868,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         cf* dst = direct_out ? out : work;
         const int64_t dplane = direct_out ? io.out_pitch : N, dshift = direct_out ? start : 0;
         {
-            const MixParams b = P > 1 ? role_b(work, N, work, N, 0, N, 0) : role_b(work, N, dst, dplane, start, stop, dshift);
+            MixParams b = P > 1 ? role_b(work, N, work, N, 0, N, 0) : role_b(work, N, dst, dplane, start, stop, dshift);
+            b.counter = ctr + 5;
             steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colmix<+1>(b, st); }});
         }
         if (P > 1) {
-            const MixParams a = role_a(work, N, dst, dplane, start, stop, dshift);
+            MixParams a = role_a(work, N, dst, dplane, start, stop, dshift);
+            a.counter = ctr + 6;
             steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
         }
         if (tail.out) {

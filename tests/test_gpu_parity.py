@@ -983,7 +983,43 @@ SMOOTH = [
 ]
 
 
-@pytest.mark.parametrize("n,n1,n2", SMOOTH)
+@pytest.fixture
+def mixed_all(monkeypatch):
+    """PBH_MIXED=2 (two-level lengths through the mixed-radix plan too) is read once per process: run the test body in a
+    child process with the variable set."""
+    import os
+    import subprocess
+    import sys
+
+    def run(code):
+        env = dict(os.environ, PBH_MIXED="2")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+    return run
+
+
+def test_7smooth_two_level_lengths(mixed_all):
+    """N1 = P * Q beyond one column tile (P > 1): both column roles of k_colmix, complex64 and complex128."""
+    out = mixed_all("""
+import numpy as np, sys
+sys.path.insert(0, "tests")
+import test_gpu_parity as t
+from pulsarbat_amd import _hip
+for n, n1, n2 in [(64800, 2025, 32), (400000, 3125, 128), (1000000, 15625, 64)]:
+    info = _hip.Plan(n, 1, 1, 0, n, device=0).info
+    assert (info["n1"], info["n2"], info["nkernel"]) == (n1, n2, 7), info
+    for tail in [(1,), (3, 2), (8, 2)]:
+        for device in (False, True):
+            t.check((n,) + tail, 3.0, 1e6, 1e9, seed=n % 97, device=device)
+t.check128((400000, 2, 2), 3.0)
+print("two-level ok")
+""")
+    assert "two-level ok" in out
+
+
+@pytest.mark.parametrize("n,n1,n2", [c for c in SMOOTH if c[1] <= 1024])
 @pytest.mark.parametrize("tail", [(1,), (3, 2), (8, 2)])
 def test_7smooth_lengths(n, n1, n2, tail):
     from pulsarbat_amd import _hip
