@@ -76,7 +76,10 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
 // VGPRs, so one workgroup's loads and stores overlap the other's stages -- the write path alone needs ~7 us for a tile, as
 // long as its stages take (a single workgroup per CU with 128-KiB tiles and deferred stores measured 1.5x slower).
 constexpr int kMixTileBytes = 65536;
-template <int DIR>
+// SEVEN: the kernel contains the radix-7 butterfly.  Its 49-term form needs more registers than the 128 a thread has here,
+// and the allocator then spills values that live across the stage switch on EVERY path, radix 7 used or not (+40 % on a
+// 5^4-point pass): lengths without a factor 7 run the variant that does not carry it.
+template <int DIR, bool SEVEN>
 __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
     constexpr int NT = 512;
     constexpr int NI = kMixTileBytes / (int)sizeof(cf) / NT;   // rows per thread at most
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
                 case 3: mix_stage<3, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 4: mix_stage<4, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 5: mix_stage<5, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
-                case 7: mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 7: if constexpr (SEVEN) mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 default: mix_stage<8, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
             }
             Lj /= r;

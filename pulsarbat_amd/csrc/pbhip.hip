@@ -677,7 +677,10 @@ static int launch_colmix(const MixParams& prm, hipStream_t st) {
                        kMixMaxStages * sizeof(int) + 16;
     int64_t tiles = (int64_t)prm.S * prm.nblock * prm.ncolgrp;
     if (tiles > 512) tiles = 512;   // persistent: two workgroups per CU
-    return launch_tile_kernel(k_colmix<DIR>, q, tiles, 512, st, (int)lds);
+    bool seven = false;
+    for (int j = 0; j < q.nstage; ++j) seven |= q.radix[j] == 7;
+    return seven ? launch_tile_kernel(k_colmix<DIR, true>, q, tiles, 512, st, (int)lds)
+                 : launch_tile_kernel(k_colmix<DIR, false>, q, tiles, 512, st, (int)lds);
 }
 
 // device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major

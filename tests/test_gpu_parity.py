@@ -1058,3 +1058,17 @@ def test_7smooth_detect_series_major_and_user_chirp():
 @pytest.mark.parametrize("n", [20000, 400000])
 def test_7smooth_c128(n):
     check128((n, 2, 2), 3.0)
+
+
+def test_native_length_list_matches_the_plans():
+    """Every length pulsarbat_amd.utils calls native gets a plan without the convolution detour (a real N1 x N2 split
+    beyond one tile), and 7-smooth neighbours outside the list are not in it."""
+    from pulsarbat_amd import _hip
+    from pulsarbat_amd.utils import _native_lens
+    lens = _native_lens(1 << 25)
+    rng = np.random.default_rng(3)
+    for n in sorted(set(rng.choice(lens, 60).tolist() + [96, 625 << 14, 600 << 14, 3 << 20])):
+        info = _hip.Plan(int(n), 1, 1, 0, int(n), device=0).info
+        assert info["n1"] * info["n2"] == n and info["n2"] <= 1 << 14, (n, info)   # (a convolution plan reports n1 = 1, n2 = n)
+    for n in (10_000_000, 16_000_000, 3 ** 15, 1000):
+        assert n not in lens

@@ -25,8 +25,9 @@ def test_fast_len():
 
 def test_native_len():
     from pulsarbat_amd.utils import next_native_len, prev_native_len
-    assert next_native_len(1) == 32 and next_native_len(33) == 64 and prev_native_len(100) == 64
-    assert next_native_len(10_000_000) == 5 << 21 and prev_native_len(10_000_000) == 1 << 23
+    assert next_native_len(1) == 32 and next_native_len(33) == 64 and prev_native_len(100) == 96   # 96 = 3 * 2^5
+    # 7-smooth lengths with one mixed-radix column pass count as native: 625 * 2^14 and 600 * 2^14 bracket 10^7
+    assert next_native_len(10_000_000) == 625 << 14 and prev_native_len(10_000_000) == 600 << 14
     assert next_native_len((3 << 20) - 5) == 3 << 20 and prev_native_len(3 << 20) == 3 << 20
     assert prev_native_len(7 << 24) == 7 << 24 and next_native_len((7 << 24) + 1) == 1 << 27
     with pytest.raises(ValueError):
