@@ -22,8 +22,15 @@ while time.time() - t0 < budget:
     else:
         os.environ.pop("PBH_QMAX", None)
     clear_plan_cache()
-    pow2 = rng.random() < 0.75
-    n = 1 << int(rng.integers(12, 23)) if pow2 else int(rng.integers(2000, 400000))
+    kind = rng.random()
+    if kind < 0.55:
+        n = 1 << int(rng.integers(12, 23))
+    elif kind < 0.8:
+        n = int(rng.integers(2000, 400000))
+    else:   # 7-smooth: the mixed-radix column pass (one level by default; both levels when run with PBH_MIXED=2)
+        from pulsarbat_amd.utils import _smooth_7
+        cand = [v for v in _smooth_7(1 << 21) if v >= 2000 and v % 32 == 0 and v & (v - 1)]
+        n = int(rng.choice(cand))
     nchan = int(rng.integers(1, 10))
     npol = int(rng.choice([1, 2]))
     dtype = np.complex64 if rng.random() < 0.7 else np.complex128
