@@ -683,6 +683,44 @@ static int launch_colmix(const MixParams& prm, hipStream_t st) {
                  : launch_tile_kernel(k_colmix<DIR, false>, q, tiles, 512, st, (int)lds);
 }
 
+// k_colmix parameters of a mixed plan's two column roles (mixed_kernels.hpp): A = the P-point stage over rows one chunk
+// N / P apart, B = the Q-point pass inside each of the P row blocks.  ld / st: planar arrays (series pitch ldp / stpl);
+// only element (time) indices in [k0, k1) are stored, at index - shift.
+static MixParams mix_role_a(const pbh_plan* p, const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1,
+                            int64_t shift) {
+    const int64_t N = p->N;
+    const int N1 = p->N1, N2 = p->N2, P = p->P;
+    MixParams m{};
+    m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
+    m.wlog2 = mix_wlog2(P, N2);
+    m.S = p->S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) >> m.wlog2;
+    m.xdiv = N2; m.ystep = 1; m.nmod = N1; m.mult = N2; m.y0mul = 0;
+    m.tw = BigTwiddle{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
+    m.tw.nmod = N;
+    m.nstage = p->mixP.nstage;
+    for (int j = 0; j < m.nstage; ++j) m.radix[j] = p->mixP.radix[j];
+    m.wl = p->mixP.wl; m.perm = p->mixP.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+    m.counter = nullptr;
+    return m;
+}
+static MixParams mix_role_b(const pbh_plan* p, const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1,
+                            int64_t shift) {
+    const int64_t N = p->N;
+    const int N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
+    MixParams m{};
+    m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
+    m.wlog2 = mix_wlog2(Q, N2);
+    m.S = p->S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 >> m.wlog2;
+    m.xdiv = 1; m.ystep = P; m.nmod = N; m.mult = 1; m.y0mul = 1;
+    m.tw = BigTwiddle{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
+    m.tw.nmod = N;
+    m.nstage = p->mixQ.nstage;
+    for (int j = 0; j < m.nstage; ++j) m.radix[j] = p->mixQ.radix[j];
+    m.wl = p->mixQ.wl; m.perm = p->mixQ.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
+    m.counter = nullptr;
+    return m;
+}
+
 // device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major
 struct IoLayout {
     int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
@@ -808,8 +846,6 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         const int64_t N = p->N, start = p->start, stop = p->stop;
         const int N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
         cf* work = p->work;
-        BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
-        tw.nmod = N;
         const bool in_sm = io.in_layout == PBH_LAYOUT_SERIES_MAJOR, out_sm = io.out_layout == PBH_LAYOUT_SERIES_MAJOR;
         const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
         if (!in_sm) {
@@ -818,30 +854,11 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 return launch_deinterleave(in, work, N, S, nvalid, st, 0, mft);
             }});
         }
-        const pbh_plan::MixTable tp = p->mixP, tq = p->mixQ;
         auto role_a = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
-            MixParams m{};
-            m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
-            m.wlog2 = mix_wlog2(P, N2);
-            m.S = S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) >> m.wlog2;
-            m.xdiv = N2; m.ystep = 1; m.nmod = N1; m.mult = N2; m.y0mul = 0;
-            m.tw = tw; m.nstage = tp.nstage;
-            for (int j = 0; j < tp.nstage; ++j) m.radix[j] = tp.radix[j];
-            m.wl = tp.wl; m.perm = tp.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
-            m.counter = nullptr;
-            return m;
+            return mix_role_a(p, ld, ldp, stp, stpl, k0, k1, shift);
         };
         auto role_b = [=](const cf* ld, int64_t ldp, cf* stp, int64_t stpl, int64_t k0, int64_t k1, int64_t shift) {
-            MixParams m{};
-            m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
-            m.wlog2 = mix_wlog2(Q, N2);
-            m.S = S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 >> m.wlog2;
-            m.xdiv = 1; m.ystep = P; m.nmod = N; m.mult = 1; m.y0mul = 1;
-            m.tw = tw; m.nstage = tq.nstage;
-            for (int j = 0; j < tq.nstage; ++j) m.radix[j] = tq.radix[j];
-            m.wl = tq.wl; m.perm = tq.perm; m.keep0 = k0; m.keep1 = k1; m.st_shift = shift;
-            m.counter = nullptr;
-            return m;
+            return mix_role_b(p, ld, ldp, stp, stpl, k0, k1, shift);
         };
         const cf* src = in_sm ? in : work;          // a series-major input is read by the first column pass, out of place
         int64_t splane = in_sm ? io.in_pitch : N;
@@ -2712,7 +2729,9 @@ static int native_fft_plan(int device, int64_t n, int64_t batch, pbh_plan** out)
 static bool native_fft_ok(int64_t n, int64_t batch) {
     static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
     if (!on || batch > 65535 || n <= kTilePoints || n > (1LL << 28)) return false;
-    return (is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0;
+    if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
+    int n1, n2, pp;   // 7-smooth lengths with rows the stand-alone row transform has (mixed_kernels.hpp)
+    return mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024;
 }
 
 // Forward transforms of a native-length plan `p` (batch = p->S series of p->N samples) up to plan order in p->work.
@@ -2722,6 +2741,25 @@ static int native_forward(pbh_plan* p, const cf* din, int il, hipStream_t st) {
     const int S = p->S, N1 = p->N1, N2 = p->N2, P = p->P, Q = N1 / P;
     const int64_t n = p->N, total = (int64_t)(S / il) * n;
     cf* work = p->work;
+    if (p->mixed) {   // 7-smooth length: k_colmix plays the column roles, the rows are the engine's
+        const cf* src = din;
+        if (il > 1) {
+            PBHCHECK(launch_deinterleave(din, work, total, il, total, st));
+            src = work;
+        }
+        unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+        HIPCHECK(hipMemsetAsync(ctr, 0, kCounterBytes, st));
+        if (P > 1) {
+            MixParams a = mix_role_a(p, src, n, work, n, 0, n, 0);
+            a.counter = ctr + 3;
+            PBHCHECK(launch_colmix<-1>(a, st));
+            src = work;
+        }
+        MixParams b = mix_role_b(p, src, n, work, n, 0, n, 0);
+        b.counter = ctr + 4;
+        PBHCHECK(launch_colmix<-1>(b, st));
+        return launch_rowfft(N2, work, p->tw16k, (int64_t)S * N1, st);
+    }
     BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, n - 1};
     tw.nmod = is_pow2(n) ? 0 : n;
     const bool fuse = P > 1 && il == S && S > 1 && radix_layout_ok(S, P, n, N2);
@@ -2784,7 +2822,9 @@ static bool stft_native_ok(int64_t n, int64_t nseg, int64_t S) {
     static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
     if (!on || n <= kTilePoints || n > (1LL << 27) || nseg * S > 0x7fffffffLL || nseg * S * (n / kTilePoints + 1) / 64 > 0x7fffffffLL)
         return false;
-    return (is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0;
+    if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
+    int n1, n2, pp;
+    return mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024;
 }
 
 static int stft_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t nseg, int64_t n, int nchan, int inner,

@@ -1072,3 +1072,15 @@ def test_native_length_list_matches_the_plans():
         assert info["n1"] * info["n2"] == n and info["n2"] <= 1 << 14, (n, info)   # (a convolution plan reports n1 = 1, n2 = n)
     for n in (10_000_000, 16_000_000, 3 ** 15, 1000):
         assert n not in lens
+
+
+@pytest.mark.parametrize("n,tail,dtype", [
+    (75 << 14, (2,), np.complex64), (81 << 12, (3,), np.complex64), (35 << 11, (2, 2), np.complex64),
+    (625 << 10, (1,), np.complex64), (45 << 13, (2,), np.complex128),
+])
+def test_fft_7smooth_lengths(n, tail, dtype):
+    """pb.fft.fft / ifft of 7-smooth lengths q * 2^k (q <= 1024, 2^k >= 1024): mixed-radix column pass + the engine's row
+    transform, no convolution ring (same numbers either way; tools/bench_fft.py shows the rate)."""
+    rng = np.random.default_rng(n % 1000 + len(tail))
+    x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(dtype)
+    _fft_check(x, 2e-6 if dtype == np.complex64 else 1e-12)
