@@ -34,6 +34,19 @@ def relerr(a, b):
     return np.linalg.norm(np.asarray(a) - b) / max(np.linalg.norm(b), 1e-30)
 
 
+_SMOOTH = None
+
+
+def smooth_len(lo, hi):
+    """A 7-smooth multiple of 32 in [lo, hi] that is not a power of two: the mixed-radix column pass (both of its levels
+    when the process runs with PBH_MIXED=2)."""
+    global _SMOOTH
+    if _SMOOTH is None:
+        from pulsarbat_amd.utils import _smooth_7
+        _SMOOTH = [v for v in _smooth_7(1 << 22) if v % 32 == 0 and v & (v - 1)]
+    return int(rng.choice([v for v in _SMOOTH if lo <= v <= hi]))
+
+
 def report(kind, ok, msg):
     global bad
     count[kind] = count.get(kind, 0) + 1
@@ -46,7 +59,7 @@ while time.time() - t0 < budget:
     kind = rng.choice(["slices", "stft", "onetile", "chirp", "incoherent", "freqshift"])
     sr, fc = float(rng.choice([1e6, 8e6])), float(rng.choice([8e8, 1.3e9]))
     if kind == "slices":
-        n = 1 << int(rng.integers(12, 19)) if rng.random() < 0.8 else int(rng.integers(3000, 100000))
+        n = 1 << int(rng.integers(12, 19)) if rng.random() < 0.6 else (int(rng.integers(3000, 100000)) if rng.random() < 0.5 else smooth_len(3000, 300000))
         nchan, npol = int(rng.integers(1, 9)), int(rng.choice([1, 2]))
         dtype = np.complex64 if rng.random() < 0.8 else np.complex128
         x = rnd((n, nchan, npol), dtype)
@@ -109,6 +122,8 @@ while time.time() - t0 < budget:
         report(kind, e < 1e-5, f"shape={shape} dm={dm} err={e:.2e}")
     elif kind == "chirp":
         n, nchan = 1 << int(rng.integers(11, 17)), int(rng.integers(1, 6))
+        if rng.random() < 0.3:
+            n = smooth_len(2000, 150000)
         shape = (n, nchan, 2)
         x = rnd(shape)
         dm = 2.0
@@ -138,6 +153,8 @@ while time.time() - t0 < budget:
         report(kind, y.shape == want.shape and np.array_equal(np.asarray(y), want), f"shape={shape} dm={dm}")
     else:
         n = 1 << int(rng.integers(12, 22))
+        if rng.random() < 0.3:
+            n = smooth_len(4000, 1 << 21)
         nchan = int(rng.choice([1, 2, 4, 8]))
         shape = (n, nchan, 2)
         if n * nchan > (1 << 23):
