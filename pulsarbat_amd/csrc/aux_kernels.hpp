@@ -23,7 +23,15 @@ struct ChirpParams {
     int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
     float* phase = nullptr;  // optional second output, same order: the chirp's phase in revolutions, [-0.5, 0.5]
     int P = 1;               // column transform split P x (N1/P): row r of a series holds k1 = r/Q + P*(r%Q)
+    int phase16 = 0;         // phase rows (2^14 bins) in k_rowp16's order: thread tau's 32 bins tau + 512 i as eight 16-byte groups,
+                             // position ((i >> 2) << 11) + 4 tau + (i & 3) -- the row is then read with 16-byte loads
 };
+__device__ __forceinline__ int64_t phase_index(int64_t d, int N2, int phase16) {
+    if (!phase16) return d;
+    const int64_t e2 = d % N2;
+    const int64_t tau = e2 & 511, i = e2 >> 9;
+    return d - e2 + (((i >> 2) << 11) + (tau << 2) + (i & 3));
+}
 
 // Row order of the planar work buffer when the column transform of length N1 is split into a radix-P stage
 // (k_radix_p) and P blocks of Q = N1/P rows (k_colq): block c, row d within it, holds k1 = c + P*d.
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
         sincospi(2.0 * fr, &sn, &cs);
         // the reference rounds the transfer function to complex64 (dedispersion.py:23) for both data dtypes
         p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
-        if (p.phase) p.phase[d] = (float)(-fr);   // chirp = exp(2 pi i phase): what k_rowp feeds to v_cos / v_sin
+        if (p.phase) p.phase[phase_index(d, p.N2, p.phase16)] = (float)(-fr);   // chirp = exp(2 pi i phase): what k_rowp feeds to v_cos / v_sin
     }
 }
 
@@ -1114,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const doub
             double sn, cs;
             sincospi(2.0 * fr, &sn, &cs);
             p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
-            if (p.phase) p.phase[d] = (float)(-fr);
+            if (p.phase) p.phase[phase_index(d, p.N2, p.phase16)] = (float)(-fr);
         } else if (mode == 1) {
             const int64_t i = (k + p.N / 2) % p.N;
             bool zero;

@@ -607,6 +607,7 @@ struct RowpParams {
     real scale;          // 1/N
     unsigned* counter;   // pair hand-out (zeroed before the launch); null = static stride
     int cP = 1;          // phase rows stored in split order cP x (N1/cP), data rows in natural order (RowParams::cP)
+    int phase16 = 0;     // the phase rows are stored in k_rowp16's order (ChirpParams::phase16): k_rowp16 runs the pass
 };
 
 template <int M, int R>
@@ -790,8 +791,13 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
             }
             const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * M, (uint32_t)(M * sizeof(float)));
 #pragma unroll
-            for (int i = 0; i < R; ++i)
-                ph[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pvoff, i * PSTEP, 0));
+            for (int j = 0; j < R / 4; ++j) {   // the row is stored in this order (ChirpParams::phase16): 8 x 16 bytes per thread
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rp, tau * 16, j * (4 * MR * (int)sizeof(float)), 0);
+                ph[4 * j] = __uint_as_float(x.x);
+                ph[4 * j + 1] = __uint_as_float(x.y);
+                ph[4 * j + 2] = __uint_as_float(x.z);
+                ph[4 * j + 3] = __uint_as_float(x.w);
+            }
         }
         // forward: 16 (pair-adjacent bases), 32, 32 -> natural distribution tau + 512 i
         if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true, false, false, NoHook, 1, true, false>(v, lds, tau, 0, wf);

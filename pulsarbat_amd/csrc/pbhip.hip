@@ -171,6 +171,7 @@ struct pbh_plan {
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
     float* chirp_phase = nullptr;  // same order, revolutions: what k_rowp reads (generated chirps only)
     bool has_phase = false;
+    bool phase16 = false;          // ... with every 2^14-bin row in k_rowp16's order (ChirpParams::phase16)
     cf* tw16k = nullptr;     // W_16384^p
     double2* tw_hi = nullptr;
     double2* tw_lo = nullptr;
@@ -420,14 +421,18 @@ static bool rowp_ok(int N1, int N2) {
     const int FR = kTilePoints / N2;
     return N2 >= 1024 && N2 <= kTilePoints && FR >= 1 && N1 >= 1;   // (a series whose N1 is not a multiple of FR ends in a short tile)
 }
+// 2^14-point rows go through k_rowp16, which reads its phase rows in its own order; PBH_ROW16=0 keeps the 8-byte-per-lane
+// kernel (A/B runs).  Decided when the chirp is written (the plan remembers: pbh_plan::phase16).
+static bool rowp16_on(int N2) {
+    static const bool row16 = [] { const char* e = getenv("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
+    return row16 && N2 == kTilePoints;
+}
 static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (int64_t)prm.nchan * ((prm.N1 + FR - 1) / FR);
     if (tiles > row_grid()) tiles = row_grid();
-    // PBH_ROW16=0 keeps the 8-byte-per-lane kernel for 2^14-point rows (A/B runs)
-    static const bool row16 = [] { const char* e = getenv("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
     static const bool nofft = [] { const char* e = getenv("PBH_ROW16_NOFFT"); return e ? atoi(e) != 0 : false; }();
-    if (row16 && M == kTilePoints)
+    if (prm.phase16 && M == kTilePoints)
         return nofft ? launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16)
                      : launch_tile_kernel(k_rowp16<PBH_R, 0>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
     switch (M) {
@@ -879,6 +884,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 #ifndef PBH_F64
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)N), ctr + 2};
+            rpp.phase16 = p->phase16;
             steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
@@ -1011,6 +1017,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colq<OP_FWD_TW>(Q, a, st); }});
                 RowpParams r{work + (int64_t)s0 * N, p->chirp_phase + (int64_t)(s0 / npol) * N, p->tw16k, 1, N1, unit,
                              (real)(1.0 / (double)p->N), ctr + ci++};
+                r.phase16 = p->phase16;
                 steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, r, st); }});
                 ColpParams b = cp3;
                 b.data = work + (int64_t)s0 * N;
@@ -1027,6 +1034,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
             rpp.cP = chirp_split;
+            rpp.phase16 = p->phase16;
             steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
@@ -1095,6 +1103,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N),
                            reinterpret_cast<unsigned*>(p->tw16k + kTwTable) + 2};
+            rpp.phase16 = p->phase16;
             steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
@@ -1864,6 +1873,8 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     if (p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
+        cp.phase16 = rowp16_on(p->N2) ? 1 : 0;
+        p->phase16 = cp.phase16 != 0;
         p->has_phase = true;
     }
 #endif
@@ -1942,6 +1953,8 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     if (mode == 0 && p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
+        cp.phase16 = rowp16_on(p->N2) ? 1 : 0;
+        p->phase16 = cp.phase16 != 0;
         phase = true;
     }
 #endif
