@@ -47,6 +47,62 @@ struct MixParams {
                         // so the tiles in flight across the chip stay a tight window of neighbouring column groups (k_colq)
 };
 
+// Odd small transforms through the symmetry of the roots: with s_a = v[a] + v[P-a], d_a = v[a] - v[P-a],
+//   X[c], X[P-c] = (v0 + sum_a cos(2 pi a c / P) s_a)  -/+  i dir (sum_a sin(2 pi a c / P) d_a),   dir = -1 forward.
+// Half the multiplications of the direct form (dft_odd, fft_core.hpp) and few values live at a time: the direct 7-point
+// form alone needed more registers than the 128 this kernel has.
+template <int P, int DIR>
+__device__ __forceinline__ void dft_odd_sym(cf (&v)[P]) {
+    constexpr int H = (P - 1) / 2;
+    cf sp[H], dm[H];
+    cf x0 = v[0];
+#pragma unroll
+    for (int a = 1; a <= H; ++a) {
+        sp[a - 1] = cadd(v[a], v[P - a]);
+        dm[a - 1] = csub(v[a], v[P - a]);
+        x0 = cadd(x0, sp[a - 1]);
+    }
+    const cf v0 = v[0];
+    v[0] = x0;
+#pragma unroll
+    for (int c = 1; c <= H; ++c) {
+        cf m = v0, n = make_cf(0, 0);
+#pragma unroll
+        for (int a = 1; a <= H; ++a) {
+            const int j = (a * c) % P;   // compile-time after unrolling
+            const real wr = OddRoots<P>::c(j), wi = OddRoots<P>::s(j);
+            m.x += wr * sp[a - 1].x;
+            m.y += wr * sp[a - 1].y;
+            n.x += wi * dm[a - 1].x;
+            n.y += wi * dm[a - 1].y;
+        }
+        // -/+ i dir n with dir = DIR:  forward (DIR = -1): X[c] = m - i n -> (m.x + n.y, m.y - n.x)
+        if (DIR < 0) {
+            v[c] = make_cf(m.x + n.y, m.y - n.x);
+            v[P - c] = make_cf(m.x - n.y, m.y + n.x);
+        } else {
+            v[c] = make_cf(m.x - n.y, m.y + n.x);
+            v[P - c] = make_cf(m.x + n.y, m.y - n.x);
+        }
+    }
+}
+template <int R, int DIR>
+struct MixDft {
+    static __device__ __forceinline__ void run(cf (&v)[R]) { Dft<R, DIR>::run(v); }
+};
+template <int DIR>
+struct MixDft<3, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[3]) { dft_odd_sym<3, DIR>(v); }
+};
+template <int DIR>
+struct MixDft<5, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[5]) { dft_odd_sym<5, DIR>(v); }
+};
+template <int DIR>
+struct MixDft<7, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[7]) { dft_odd_sym<7, DIR>(v); }
+};
+
 template <int R, int DIR>
 __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, int wlog2, int tid, int nthreads) {
     const int m = Lj / R, tws = L / Lj;
@@ -59,7 +115,7 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
         cf v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = base[u * es];
-        Dft<R, DIR>::run(v);
+        MixDft<R, DIR>::run(v);
         if (m > 1) {
 #pragma unroll
             for (int u = 1; u < R; ++u) {
@@ -76,10 +132,7 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
 // VGPRs, so one workgroup's loads and stores overlap the other's stages -- the write path alone needs ~7 us for a tile, as
 // long as its stages take (a single workgroup per CU with 128-KiB tiles and deferred stores measured 1.5x slower).
 constexpr int kMixTileBytes = 65536;
-// SEVEN: the kernel contains the radix-7 butterfly.  Its 49-term form needs more registers than the 128 a thread has here,
-// and the allocator then spills values that live across the stage switch on EVERY path, radix 7 used or not (+40 % on a
-// 5^4-point pass): lengths without a factor 7 run the variant that does not carry it.
-template <int DIR, bool SEVEN>
+template <int DIR>
 __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
     constexpr int NT = 512;
     constexpr int NI = kMixTileBytes / (int)sizeof(cf) / NT;   // rows per thread at most
@@ -174,7 +227,7 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
                 case 3: mix_stage<3, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 4: mix_stage<4, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 5: mix_stage<5, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
-                case 7: if constexpr (SEVEN) mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 7: mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 default: mix_stage<8, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
             }
             Lj /= r;

@@ -125,9 +125,9 @@ static bool is_7smooth(int64_t n) {
     return n == 1;
 }
 static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
-    // PBH_MIXED: 0 = off, 1 (default) = lengths whose N1 fits one column pass (P = 1: 5 passes, 1.3x the rate of the padded
-    // convolution), 2 = two-level lengths as well (7 passes: correct, tested, but not yet faster than the convolution plan)
-    static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 1; }();
+    // PBH_MIXED: 0 = off, 1 = only lengths whose N1 fits one column pass (P = 1: 5 passes, 1.5x the rate of the padded
+    // convolution), 2 (default) = two-level lengths as well (7 passes: 1.06-1.14x the convolution plan, half its memory)
+    static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 2; }();
     if (!mode || n < 64 || is_pow2(n) || !is_7smooth(n)) return false;
     int k = 0;
     while (((n >> k) & 1) == 0) ++k;
@@ -682,10 +682,7 @@ static int launch_colmix(const MixParams& prm, hipStream_t st) {
                        kMixMaxStages * sizeof(int) + 16;
     int64_t tiles = (int64_t)prm.S * prm.nblock * prm.ncolgrp;
     if (tiles > 512) tiles = 512;   // persistent: two workgroups per CU
-    bool seven = false;
-    for (int j = 0; j < q.nstage; ++j) seven |= q.radix[j] == 7;
-    return seven ? launch_tile_kernel(k_colmix<DIR, true>, q, tiles, 512, st, (int)lds)
-                 : launch_tile_kernel(k_colmix<DIR, false>, q, tiles, 512, st, (int)lds);
+    return launch_tile_kernel(k_colmix<DIR>, q, tiles, 512, st, (int)lds);
 }
 
 // k_colmix parameters of a mixed plan's two column roles (mixed_kernels.hpp): A = the P-point stage over rows one chunk
