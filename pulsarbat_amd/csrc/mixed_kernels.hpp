@@ -107,9 +107,12 @@ template <int R, int DIR>
 __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, int wlog2, int tid, int nthreads) {
     const int m = Lj / R, tws = L / Lj;
     const int nbf = (L / R) << wlog2;
+    const float inv_m = 1.0f / (float)m;
     for (int b = tid; b < nbf; b += nthreads) {
         const int col = b & ((1 << wlog2) - 1), q = b >> wlog2;
-        const int blk = q / m, i = q - blk * m;
+        // q / m without the integer division: q < 1024 and m <= 512, so (q + 0.5) / m is at least 1e-3 away from an integer
+        // and the float32 product (error < 1e-4) truncates to the exact quotient
+        const int blk = (int)(((float)q + 0.5f) * inv_m), i = q - blk * m;
         cf* base = lds + (((blk * Lj + i)) << wlog2) + col;
         const int es = m << wlog2;
         cf v[R];
@@ -117,9 +120,10 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
         for (int u = 0; u < R; ++u) v[u] = base[u * es];
         MixDft<R, DIR>::run(v);
         if (m > 1) {
+            const int iw = i * tws;
 #pragma unroll
             for (int u = 1; u < R; ++u) {
-                const cf w = wl[i * u * tws];   // i u < Lj: the index stays below L
+                const cf w = wl[iw * u];   // i u < Lj: the index stays below L
                 v[u] = cmul(v[u], DIR < 0 ? w : cconj(w));
             }
         }

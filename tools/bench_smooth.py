@@ -27,7 +27,7 @@ def run(n, nchan=8, npol=2, dm=56.77, band=400e6, center=1.4e9):
     k = plan.profile(x, y, iters=5)
     tot = sum(ms for _, ms in k)
     info = plan.info
-    print(json.dumps({"PBH_MIXED": os.environ.get("PBH_MIXED", "1"), "shape": [n, nchan, npol], "n1": info["n1"], "n2": info["n2"],
+    print(json.dumps({"PBH_MIXED": os.environ.get("PBH_MIXED", "default (2)"), "shape": [n, nchan, npol], "n1": info["n1"], "n2": info["n2"],
                       "nkernel": info["nkernel"], "ms": round(tot, 3), "Gsamples_per_s": round(n * nchan * npol / tot / 1e6, 1),
                       "kernels": {a: round(b, 3) for a, b in k}}), flush=True)
     plan.close()
