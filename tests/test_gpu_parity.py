@@ -369,7 +369,8 @@ def test_detect_scrunch_modes(mode, k):
 
 
 @pytest.mark.parametrize("shape,chunk,dm", [((1 << 18, 4, 2), 1 << 15, 20.0), ((300000, 2, 2), 1 << 16, 50.0),
-                                            ((1 << 16, 3), 1 << 14, 5.0)])
+                                            ((1 << 16, 3), 1 << 14, 5.0),
+                                            ((200000, 4, 2), 20000, 5.0), ((300000, 2, 2), 64800, 8.0)])   # 7-smooth chunks (k_colmix, one and two levels)
 def test_stream_overlap_save(shape, chunk, dm):
     """BASELINE configs[3] (overlap-save streaming) at small size: equals the concatenation of
     per-chunk reference calls, and is time-contiguous with the single-call result."""
