@@ -9,10 +9,10 @@ P = os.path.join(ROOT, "profiles")
 
 
 def test_rocprof_agrees_with_bench_line():
-    bench = json.loads(open(os.path.join(P, "r02z2_bench.json")).read().strip().splitlines()[-1])
+    bench = json.loads(open(os.path.join(P, "r02z3_bench.json")).read().strip().splitlines()[-1])
     roof = bench["roofline"]
     assert roof["kernel"] == "k_row_fused"
-    rows = list(csv.DictReader(open(os.path.join(P, "r02z2_planar5_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(P, "r02z3_planar5_kernel_stats.csv"))))
     row = [r for r in rows if "k_rowp16<" in r["Name"]]
     assert len(row) == 1
     avg_ms = float(row[0]["AverageNs"]) / 1e6
