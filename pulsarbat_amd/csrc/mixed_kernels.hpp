@@ -86,21 +86,63 @@ __device__ __forceinline__ void dft_odd_sym(cf (&v)[P]) {
         }
     }
 }
+// Composite odd radix 9 = 3 x 3: two register levels per LDS round trip, in place (written for any R = P * P) with
+// n = P n1 + n2, k = k1 + P k2: the P-point transforms over n1 leave A[k1][n2] at position P k1 + n2; times W_R^{n2 k1} (read
+// from the W_L table: R divides L; one address for all lanes); the transforms over n2 leave X[k1 + P k2] at position
+// P k1 + k2 -- the caller stores position p at output index (p / P) + P (p % P).
+template <int P, int DIR>
+__device__ __forceinline__ void dft_square(cf (&v)[P * P], const cf* wl, int L) {
+    const int ts = L / (P * P);
+#pragma unroll
+    for (int n2 = 0; n2 < P; ++n2) {
+        cf t[P];
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) t[n1] = v[P * n1 + n2];
+        dft_odd_sym<P, DIR>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) {
+            if (n2 * k1 != 0) {
+                const cf w = wl[n2 * k1 * ts];
+                t[k1] = cmul(t[k1], DIR < 0 ? w : cconj(w));
+            }
+            v[P * k1 + n2] = t[k1];
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) {
+        cf t[P];
+#pragma unroll
+        for (int n2 = 0; n2 < P; ++n2) t[n2] = v[P * k1 + n2];
+        dft_odd_sym<P, DIR>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < P; ++k2) v[P * k1 + k2] = t[k2];
+    }
+}
+// MixDft<R>::run leaves output index out_index(p) at register position p
 template <int R, int DIR>
 struct MixDft {
-    static __device__ __forceinline__ void run(cf (&v)[R]) { Dft<R, DIR>::run(v); }
+    static __device__ __forceinline__ void run(cf (&v)[R], const cf*, int) { Dft<R, DIR>::run(v); }
+    static constexpr int out_index(int p) { return p; }
 };
 template <int DIR>
 struct MixDft<3, DIR> {
-    static __device__ __forceinline__ void run(cf (&v)[3]) { dft_odd_sym<3, DIR>(v); }
+    static __device__ __forceinline__ void run(cf (&v)[3], const cf*, int) { dft_odd_sym<3, DIR>(v); }
+    static constexpr int out_index(int p) { return p; }
 };
 template <int DIR>
 struct MixDft<5, DIR> {
-    static __device__ __forceinline__ void run(cf (&v)[5]) { dft_odd_sym<5, DIR>(v); }
+    static __device__ __forceinline__ void run(cf (&v)[5], const cf*, int) { dft_odd_sym<5, DIR>(v); }
+    static constexpr int out_index(int p) { return p; }
 };
 template <int DIR>
 struct MixDft<7, DIR> {
-    static __device__ __forceinline__ void run(cf (&v)[7]) { dft_odd_sym<7, DIR>(v); }
+    static __device__ __forceinline__ void run(cf (&v)[7], const cf*, int) { dft_odd_sym<7, DIR>(v); }
+    static constexpr int out_index(int p) { return p; }
+};
+template <int DIR>
+struct MixDft<9, DIR> {
+    static __device__ __forceinline__ void run(cf (&v)[9], const cf* wl, int L) { dft_square<3, DIR>(v, wl, L); }
+    static constexpr int out_index(int p) { return p / 3 + 3 * (p % 3); }
 };
 
 template <int R, int DIR>
@@ -118,17 +160,20 @@ __device__ __forceinline__ void mix_stage(cf* lds, const cf* wl, int L, int Lj, 
         cf v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = base[u * es];
-        MixDft<R, DIR>::run(v);
+        MixDft<R, DIR>::run(v, wl, L);
         if (m > 1) {
             const int iw = i * tws;
 #pragma unroll
-            for (int u = 1; u < R; ++u) {
-                const cf w = wl[iw * u];   // i u < Lj: the index stays below L
-                v[u] = cmul(v[u], DIR < 0 ? w : cconj(w));
+            for (int q2 = 1; q2 < R; ++q2) {
+                const int u = MixDft<R, DIR>::out_index(q2);
+                if (u != 0) {
+                    const cf w = wl[iw * u];   // i u < Lj: the index stays below L
+                    v[q2] = cmul(v[q2], DIR < 0 ? w : cconj(w));
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < R; ++u) base[u * es] = v[u];
+        for (int q2 = 0; q2 < R; ++q2) base[MixDft<R, DIR>::out_index(q2) * es] = v[q2];
     }
 }
 
@@ -232,6 +277,7 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
                 case 4: mix_stage<4, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 5: mix_stage<5, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 case 7: mix_stage<7, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
+                case 9: mix_stage<9, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
                 default: mix_stage<8, DIR>(lds, wl, L, Lj, p.wlog2, tid, NT); break;
             }
             Lj /= r;

@@ -1447,6 +1447,10 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t) {
     t->L = L;
     t->nstage = 0;
     int left = L;
+    // radix 9 = 3 x 3 in registers: two levels per LDS round trip (PBH_MIX_SQUARE=0: radix 3 only, for A/B runs).  The same
+    // for 25 = 5 x 5 needs more registers than two workgroups per CU leave (230-400 B/lane of scratch): not built.
+    static const bool square = [] { const char* e = getenv("PBH_MIX_SQUARE"); return e ? atoi(e) != 0 : true; }();
+    if (square) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
     for (int r : {7, 5, 3}) while (left % r == 0) { if (t->nstage >= kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "too many stages"); t->radix[t->nstage++] = r; left /= r; }
     while (left % 8 == 0) { t->radix[t->nstage++] = 8; left /= 8; }
     while (left % 4 == 0) { t->radix[t->nstage++] = 4; left /= 4; }
