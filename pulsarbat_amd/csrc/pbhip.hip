@@ -519,8 +519,11 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
         case 64: return launch_deint_blk<64>(in, work, N, S, plane, nvalid, st);
     }
     const int TN = tr_rows(S);
+    int64_t done = 0;
 #ifndef PBH_F64
-    if ((S & (S - 1)) == 0 && S <= 128 && N % TN == 0) {
+    // the power-of-two row transposes take whole tiles; a length that is not a multiple of the tile (7-smooth lengths with
+    // few factors of two) leaves its last samples to the generic kernel (the mixer rides in whole-tile launches only)
+    if ((S & (S - 1)) == 0 && S <= 128 && (N % TN == 0 || (!mix_ft && N >= TN))) {
         const unsigned grid = (unsigned)(N / TN);
         switch (S) {
 #define X(s) case s: if (mix_ft) hipLaunchKernelGGL((k_deinterleave_p2<s, true>), dim3(grid), dim3(256), 0, st, in, work, N, plane, nvalid, mix_ft); \
@@ -529,11 +532,12 @@ static int launch_deinterleave(const cf* in, cf* work, int64_t N, int S, int64_t
 #undef X
         }
         HIPCHECK(hipGetLastError());
-        return PBH_OK;
+        done = (int64_t)grid * TN;
+        if (done == N) return PBH_OK;
     }
 #endif
-    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N + TN - 1) / TN)), dim3(256),
-                       (size_t)TN * (S + 1) * sizeof(cf), st, in, work, N, S, TN, plane, nvalid);
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((N - done + TN - 1) / TN)), dim3(256),
+                       (size_t)TN * (S + 1) * sizeof(cf), st, in + done * S, work + done, N - done, S, TN, plane, nvalid - done);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
