@@ -239,9 +239,14 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
         int64_t s, x0; int c;
         const int64_t e0 = tile_origin(T, s, c, x0);
         // inter-pass twiddle of this thread's rows tau + RL i: z_i = zb * zs^i (float64 recurrence)
+        // (forward: the seeds are used after the stages and looked up there -- eight registers less across the stage
+        //  butterflies, which is what the forward kernel spilled)
         const int64_t xx = (x0 + f) / p.xdiv, y0 = (int64_t)c * p.y0mul;
-        const double2 zb = big_tw(p.tw, ((xx * (y0 + p.ystep * tau)) % p.nmod) * p.mult);
-        const double2 zs = big_tw(p.tw, ((xx * ((p.ystep * RL) % p.nmod)) % p.nmod) * p.mult);
+        double2 zb = make_double2(1, 0), zs = make_double2(1, 0);
+        if (DIR > 0) {
+            zb = big_tw(p.tw, ((xx * (y0 + p.ystep * tau)) % p.nmod) * p.mult);
+            zs = big_tw(p.tw, ((xx * ((p.ystep * RL) % p.nmod)) % p.nmod) * p.mult);
+        }
         {
             double2 z = zb;
             cf* dl = lds + tau * W + f;
@@ -282,6 +287,13 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
             }
             Lj /= r;
             __syncthreads();
+        }
+        if (DIR < 0) {
+            int fl = f, tl = tau;
+            asm volatile("" : "+v"(fl), "+v"(tl));   // (recomputed here, not carried across the stages)
+            const int64_t xo = (x0 + fl) / p.xdiv;
+            zb = big_tw(p.tw, ((xo * (y0 + p.ystep * tl)) % p.nmod) * p.mult);
+            zs = big_tw(p.tw, ((xo * ((p.ystep * RL) % p.nmod)) % p.nmod) * p.mult);
         }
         {
             // stores: element (time) index t = e0 + f + k rstride goes to st[t - st_shift] when keep0 <= t < keep1
