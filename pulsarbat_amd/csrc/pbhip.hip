@@ -419,7 +419,8 @@ static bool row_phase_enabled() {
 // rows of M = N2 points, 2^tile / M of them (consecutive k1 of one series) per tile
 static bool rowp_ok(int N1, int N2) {
     const int FR = kTilePoints / N2;
-    return N2 >= 1024 && N2 <= kTilePoints && FR >= 1 && N1 >= 1;   // (a series whose N1 is not a multiple of FR ends in a short tile)
+    return N2 >= 32 && N2 <= kTilePoints && FR >= 1 && N1 >= 1;   // (a series whose N1 is not a multiple of FR ends in a short tile;
+                                                                  //  rows shorter than 1024 points only occur in 7-smooth plans)
 }
 // 2^14-point rows go through k_rowp16, which reads its phase rows in its own order; PBH_ROW16=0 keeps the 8-byte-per-lane
 // kernel (A/B runs).  Decided when the chirp is written (the plan remembers: pbh_plan::phase16).
@@ -438,6 +439,7 @@ static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_rowp<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)
+        FOR_ROW_SHORT(X)
 #undef X
     }
     return fail(PBH_ERR_UNSUPPORTED, "phase row pass length " + std::to_string(M));
