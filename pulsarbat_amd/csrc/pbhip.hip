@@ -137,9 +137,14 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     if (n1 < 2) return false;
     int64_t q = 0;
     if (n1 <= kMixMaxLen) q = n1;
-    else
-        for (int64_t d = kMixMaxLen; d >= 2; --d)
-            if (n1 % d == 0 && n1 / d <= kMixMaxLen) { q = d; break; }
+    else {
+        // two levels: both factors within 512 rows if there is such a split (tiles of whole 128-byte lines in both passes;
+        // beyond 512 rows a tile holds 64-byte pieces), the larger one as the Q-point pass
+        for (int64_t d = 512; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= 512) q = d;
+        for (int64_t d = kMixMaxLen; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= kMixMaxLen) q = d;
+    }
     if (!q) return false;
     if (mode < 2 && n1 / q > 1) return false;
     *N2 = 1 << k;
