@@ -23,6 +23,7 @@ struct ChirpParams {
     int perm_w;  // 0: row position e2 holds bin k2 = e2;  W: position e2 holds k2 = e2/(N2/W) + W*(e2 % (N2/W))
     float* phase = nullptr;  // optional second output, same order: the chirp's phase in revolutions, [-0.5, 0.5]
     int P = 1;               // column transform split P x (N1/P): row r of a series holds k1 = r/Q + P*(r%Q)
+    const unsigned short* row_perm = nullptr;   // see row_bin
     int phase16 = 0;         // phase rows (2^14 bins) in k_rowp16's order: thread tau's 32 bins tau + 512 i as eight 16-byte groups,
                              // position ((i >> 2) << 11) + 4 tau + (i & 3) -- the row is then read with 16-byte loads
 };
@@ -41,7 +42,10 @@ __device__ __forceinline__ int64_t row_k1(int64_t r, int P, int N1) {
     return r / Q + (int64_t)P * (r % Q);
 }
 
-__device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w) {
+// row_perm (7-smooth plans whose rows are transformed by k_rowmix): position e2 of a row holds bin row_perm[e2], the
+// digit-reversed order its forward decimation-in-frequency stages leave (and its inverse stages start from)
+__device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w, const unsigned short* row_perm = nullptr) {
+    if (row_perm) return row_perm[e2];
     if (perm_w == 0) return e2;
     const int mw = N2 / perm_w;
     return e2 / mw + (int64_t)perm_w * (e2 % mw);
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / p.N);
         const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w);
+        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w, p.row_perm);
         const int64_t k = row_k1(r, p.P, p.N1) + (int64_t)p.N1 * k2;
         const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
         const double f = p.chan_freq[chan] + (double)bin * p.inv_ndt;
@@ -76,13 +80,14 @@ template <typename TNAT>
 __global__ __launch_bounds__(256) void k_chirp_reorder(const TNAT* __restrict__ nat_in, TNAT* __restrict__ nat_out,
                                                        const cf* __restrict__ plan_in, cf* __restrict__ plan_out,
                                                        int64_t N, int N1, int N2, int nchan, real scale,
-                                                       int to_plan, int perm_w, int P) {
+                                                       int to_plan, int perm_w, int P,
+                                                       const unsigned short* __restrict__ row_perm = nullptr) {
     const int64_t total = N * nchan;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / N);
         const int64_t e = d - (int64_t)chan * N;
-        const int64_t r = e / N2, k2 = row_bin(e - r * N2, N2, perm_w);
+        const int64_t r = e / N2, k2 = row_bin(e - r * N2, N2, perm_w, row_perm);
         const int64_t k = row_k1(r, P, N1) + (int64_t)N1 * k2;
         const int64_t nat = k * nchan + chan;
         if (to_plan) {
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_chirp_special(ChirpParams p, const doub
          d += (int64_t)gridDim.x * blockDim.x) {
         const int chan = (int)(d / p.N);
         const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w);
+        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w, p.row_perm);
         const int64_t k = row_k1(r, p.P, p.N1) + (int64_t)p.N1 * k2;
         const double a = arg[chan];
         if (mode == 0) {

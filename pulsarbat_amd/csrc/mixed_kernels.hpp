@@ -32,7 +32,8 @@ struct MixParams {
     int64_t rstride;    // elements between consecutive rows
     int nblock;         // row blocks per series (role B: P blocks of Q rows), block c at c * bstride
     int64_t bstride;
-    int64_t ncolgrp;    // column groups (W columns each) per block
+    int64_t ncolgrp;    // column groups (W columns each) per block; the last one is short when W does not divide ncols
+    int64_t ncols;      // columns of a block (role A: N / P, role B: N2)
     int wlog2;          // W = 2^wlog2 columns per tile: whole 128-byte lines, L * W <= 2^14 points
     // twiddle exponent of (row k, column position x): ((x / xdiv) * (c * y0mul + ystep * k) % nmod) * mult, looked up in tw
     int64_t xdiv, ystep, nmod, mult;
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
     const int ni = (L + RL - 1) / RL;               // sweeps over the tile (uniform)
     const int64_t tstep = (int64_t)RL * p.rstride;
 
+    // columns of a short last group: out-of-range offset (loads return zero, stores are dropped)
+    auto col_off = [&](int64_t x0) -> int { return x0 + f < p.ncols ? voff : (int)0x80000000; };
     int64_t T = blockIdx.x;
     if (T >= ntile) return;
     int64_t Tn = T + gridDim.x;
@@ -231,9 +234,10 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
         int64_t s, x0; int c;
         const int64_t e0 = tile_origin(T, s, c, x0);
         const rsrc_t rd = make_rsrc(p.ld + s * p.ld_plane + e0, tile_bytes);
+        const int vo = col_off(x0);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (i < ni) v[i] = buf_load(rd, voff, i * sweep);
+            if (i < ni) v[i] = buf_load(rd, vo, i * sweep);
     }
     while (true) {
         int64_t s, x0; int c;
@@ -268,9 +272,10 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
             int64_t s2, x2; int c2;
             const int64_t e2 = tile_origin(Tn, s2, c2, x2);
             const rsrc_t rd = make_rsrc(p.ld + s2 * p.ld_plane + e2, tile_bytes);
+            const int vo = col_off(x2);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                if (i < ni) v[i] = buf_load(rd, voff, i * sweep);
+                if (i < ni) v[i] = buf_load(rd, vo, i * sweep);
         }
         __syncthreads();
         int Lj = L;
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
             // stores: element (time) index t = e0 + f + k rstride goes to st[t - st_shift] when keep0 <= t < keep1
             const rsrc_t ro = make_rsrc(p.st + s * p.st_plane + e0 - p.st_shift, tile_bytes);
             const int64_t ot0 = e0 + f + (int64_t)tau * p.rstride;
+            const int vst = col_off(x0);
             double2 z = zb;
             constexpr int CH = NI < 8 ? NI : 8;   // a chunk of rows at a time: permutation entries, then the values, then the stores
 #pragma unroll
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
                             z = zmul(z, zs);
                         }
                         const int64_t t = ot0 + (i0 + i) * tstep;
-                        buf_store(ro, (t >= p.keep0 && t < p.keep1) ? voff : (int)0x80000000, (i0 + i) * sweep, o);   // out of range = dropped
+                        buf_store(ro, (t >= p.keep0 && t < p.keep1) ? vst : (int)0x80000000, (i0 + i) * sweep, o);   // out of range = dropped
                     }
                 }
             }
@@ -333,6 +339,136 @@ __global__ __launch_bounds__(512, 4) void k_colmix(MixParams p) {
         Tn = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)slot[0]);
         __syncthreads();   // ... and everyone has the slot before thread 0 writes it again
     }
+}
+
+// ---- fused row pass of the 7-smooth plans whose power-of-two part is too small for the 2^k engine's rows ------------------
+// N = N1 * N2 with N2 = 2^k * odd (k = 3 or 4: 8- or 16-element pieces for the column passes) and at most 1024 points: the
+// rows are transformed by mixed-radix stages too.  A tile is FR consecutive rows of the planar work buffer -- ONE contiguous
+// run of FR * N2 elements -- in LDS as it lies in memory.  Forward decimation-in-frequency stages leave every row in
+// digit-reversed order; the chirp is stored in that order (ChirpParams::row_perm), so the product is element by element;
+// the inverse runs the same stages backwards as decimation-in-time (conjugate twiddle first, inverse butterfly after),
+// which takes the digit-reversed order back to the natural one: no permutation anywhere.
+struct RowMixParams {
+    cf* data;            // planar rows, in place: row g at g * N2
+    const cf* chirp;     // plan order [chan][row][position], pre-scaled by 1/N
+    int64_t nrows;       // S * N1
+    int N1, npol, N2;
+    int FR;              // rows per tile: FR * N2 <= the tile budget
+    int nstage;
+    int radix[kMixMaxStages];   // forward order; radices 7, 5, 3, 8, 4, 2
+    const cf* wl;        // W_N2^p
+};
+
+// one stage over every row of the tile: butterfly b = (row, q); INV = false: transform then twiddle (DIF), true: conjugate
+// twiddle then inverse transform (DIT, undoing the matching forward stage)
+template <int R, bool INV>
+__device__ __forceinline__ void rowmix_stage(cf* lds, const cf* wl, int N2, int Lj, int rows, int tid, int nthreads) {
+    const int m = Lj / R, tws = N2 / Lj, per_row = N2 / R;
+    const int nbf = rows * per_row;
+    const float inv_m = 1.0f / (float)m, inv_pr = 1.0f / (float)per_row;
+    for (int b = tid; b < nbf; b += nthreads) {
+        const int row = (int)(((float)b + 0.5f) * inv_pr), q = b - row * per_row;   // (exact: b < 2^13, see mix_stage)
+        const int blk = (int)(((float)q + 0.5f) * inv_m), i = q - blk * m;
+        cf* base = lds + row * N2 + blk * Lj + i;
+        cf v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = base[u * m];
+        const int iw = i * tws;
+        if (INV && m > 1) {
+#pragma unroll
+            for (int u = 1; u < R; ++u) v[u] = cmul(v[u], cconj(wl[iw * u]));
+        }
+        if (INV) MixDft<R, +1>::run(v, wl, N2);
+        else MixDft<R, -1>::run(v, wl, N2);
+        if (!INV && m > 1) {
+#pragma unroll
+            for (int u = 1; u < R; ++u) v[u] = cmul(v[u], wl[iw * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) base[u * m] = v[u];
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void rowmix_stage_r(int r, cf* lds, const cf* wl, int N2, int Lj, int rows, int tid, int nthreads) {
+    switch (r) {
+        case 2: rowmix_stage<2, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 3: rowmix_stage<3, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 4: rowmix_stage<4, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 5: rowmix_stage<5, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 7: rowmix_stage<7, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 8: rowmix_stage<8, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        default: break;
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
+    constexpr int NT = 512;
+    constexpr int NI = kMixTileBytes / (int)sizeof(cf) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int N2 = p.N2, FR = p.FR, tid = threadIdx.x;
+    cf* wl = lds + FR * N2;
+    int* srad = reinterpret_cast<int*>(wl + N2);   // radix and sub-length of every stage
+    int* slen = srad + kMixMaxStages;
+    for (int k = tid; k < N2; k += NT) wl[k] = p.wl[k];
+    if (tid < kMixMaxStages) {
+        int r = 1, len = N2;
+#pragma unroll
+        for (int j = 0; j < kMixMaxStages; ++j) {
+            const int rj = j < p.nstage ? p.radix[j] : 1;
+            if (tid == j) { r = rj; slen[tid] = len; }
+            len /= rj;
+        }
+        srad[tid] = r;
+    }
+    const int64_t ntile = (p.nrows + FR - 1) / FR;
+    const int tile_elems = FR * N2;
+    const float inv_n2 = 1.0f / (float)N2;
+    for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int64_t g0 = t * FR;
+        const int rows = (int)(p.nrows - g0 < FR ? p.nrows - g0 : FR);
+        const int cnt = rows * N2;
+        cf* src = p.data + g0 * N2;
+        // this tile's samples and its chirp values (consumed after the forward stages)
+        cf v[NI], c[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + NT * i;
+            if (e < cnt) {
+                v[i] = src[e];
+                const int row = (int)(((float)e + 0.5f) * inv_n2);          // exact: e < 2^13
+                const int64_t g = g0 + row, srs = g / p.N1, r = g - srs * p.N1;
+                c[i] = p.chirp[((srs / p.npol) * p.N1 + r) * (int64_t)N2 + (e - row * N2)];
+            }
+        }
+        __syncthreads();   // the previous tile's stores have read LDS
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + NT * i;
+            if (e < cnt) lds[e] = v[i];
+        }
+        __syncthreads();
+        for (int j = 0; j < p.nstage; ++j) {
+            rowmix_stage_r<false>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + NT * i;
+            if (e < cnt) lds[e] = cmul(lds[e], c[i]);
+        }
+        __syncthreads();
+        for (int j = p.nstage - 1; j >= 0; --j) {
+            rowmix_stage_r<true>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + NT * i;
+            if (e < cnt) src[e] = lds[e];
+        }
+    }
+    (void)tile_elems;
 }
 
 }  // namespace PBH_NS

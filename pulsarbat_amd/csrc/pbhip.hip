@@ -153,6 +153,43 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     return true;
 }
 
+// 7-smooth lengths with only three or four factors of two: no power-of-two rows of 32 points, so the rows are mixed-radix too
+// (k_rowmix): N2 = 2^k * f, f odd, at most 1024 points, as long as possible such that N1 = N / N2 still splits into column
+// levels of at most 1024 rows.  The column passes then work on pieces of 2^k elements (64 or 128 bytes).  PBH_ROWMIX=0: off.
+static bool split_levels(int64_t n1, int64_t* qout) {
+    int64_t q = 0;
+    if (n1 <= kMixMaxLen) q = n1;
+    else {
+        for (int64_t d = 512; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= 512) q = d;
+        for (int64_t d = kMixMaxLen; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= kMixMaxLen) q = d;
+    }
+    *qout = q;
+    return q != 0;
+}
+static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
+    static const bool on = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) != 0 : true; }();
+    static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 2; }();
+    if (!on || mode < 2 || n < 4096 || is_pow2(n) || !is_7smooth(n)) return false;
+    int k = 0;
+    while (((n >> k) & 1) == 0) ++k;
+    if (k < 3) return false;
+    if (k > 4) k = 4;
+    const int64_t two = 1LL << k, odd = n >> k;
+    for (int64_t f = 1024 / two; f >= 3; --f) {
+        if (!(f & 1) || odd % f) continue;
+        const int64_t n2 = two * f, n1 = n / n2;
+        int64_t q;
+        if (n1 < 2 || !split_levels(n1, &q)) continue;
+        *N2 = (int)n2;
+        *N1 = (int)n1;
+        *P = (int)(n1 / q);
+        return true;
+    }
+    return false;
+}
+
 // ---- plan ------------------------------------------------------------------------------------------------
 constexpr size_t kCounterBytes = 4096;   // tile hand-out counters of the persistent kernels, behind the stage twiddle table
 constexpr int kCounters = (int)(kCounterBytes / sizeof(unsigned));
@@ -210,6 +247,10 @@ struct pbh_plan {
     };
     bool mixed = false;
     MixTable mixP, mixQ;
+    // ... and, when the length has too few factors of two for the 2^k engine's rows, the rows as well (k_rowmix): mixR.perm
+    // is then the chirp's row order (position -> bin)
+    bool rowmix = false;
+    MixTable mixR;
 };
 
 static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
@@ -696,6 +737,22 @@ static int launch_colmix(const MixParams& prm, hipStream_t st) {
     return launch_tile_kernel(k_colmix<DIR>, q, tiles, 512, st, (int)lds);
 }
 
+static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st) {
+    RowMixParams r{};
+    r.data = work;
+    r.chirp = p->chirp;
+    r.nrows = (int64_t)p->S * p->N1;
+    r.N1 = p->N1; r.npol = p->npol; r.N2 = p->N2;
+    r.FR = (kMixTileBytes / (int)sizeof(cf)) / p->N2;
+    r.nstage = p->mixR.nstage;
+    for (int j = 0; j < r.nstage; ++j) r.radix[j] = p->mixR.radix[j];
+    r.wl = p->mixR.wl;
+    const size_t lds = ((size_t)r.FR * p->N2 + p->N2) * sizeof(cf) + 2 * kMixMaxStages * sizeof(int) + 16;
+    int64_t tiles = (r.nrows + r.FR - 1) / r.FR;
+    if (tiles > 2048) tiles = 2048;
+    return launch_tile_kernel(k_rowmix, r, tiles, 512, st, (int)lds);
+}
+
 // k_colmix parameters of a mixed plan's two column roles (mixed_kernels.hpp): A = the P-point stage over rows one chunk
 // N / P apart, B = the Q-point pass inside each of the P row blocks.  ld / st: planar arrays (series pitch ldp / stpl);
 // only element (time) indices in [k0, k1) are stored, at index - shift.
@@ -706,7 +763,8 @@ static MixParams mix_role_a(const pbh_plan* p, const cf* ld, int64_t ldp, cf* st
     MixParams m{};
     m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
     m.wlog2 = mix_wlog2(P, N2);
-    m.S = p->S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (N / P) >> m.wlog2;
+    m.ncols = N / P;
+    m.S = p->S; m.L = P; m.rstride = N / P; m.nblock = 1; m.bstride = 0; m.ncolgrp = (m.ncols + (1 << m.wlog2) - 1) >> m.wlog2;
     m.xdiv = N2; m.ystep = 1; m.nmod = N1; m.mult = N2; m.y0mul = 0;
     m.tw = BigTwiddle{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
     m.tw.nmod = N;
@@ -723,7 +781,8 @@ static MixParams mix_role_b(const pbh_plan* p, const cf* ld, int64_t ldp, cf* st
     MixParams m{};
     m.ld = ld; m.ld_plane = ldp; m.st = stp; m.st_plane = stpl;
     m.wlog2 = mix_wlog2(Q, N2);
-    m.S = p->S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = N2 >> m.wlog2;
+    m.ncols = N2;
+    m.S = p->S; m.L = Q; m.rstride = N2; m.nblock = P; m.bstride = (int64_t)Q * N2; m.ncolgrp = (m.ncols + (1 << m.wlog2) - 1) >> m.wlog2;
     m.xdiv = 1; m.ystep = P; m.nmod = N; m.mult = 1; m.y0mul = 1;
     m.tw = BigTwiddle{p->tw_hi, p->tw_lo, p->tw_shift, N - 1};
     m.tw.nmod = N;
@@ -876,6 +935,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         const cf* src = in_sm ? in : work;          // a series-major input is read by the first column pass, out of place
         int64_t splane = in_sm ? io.in_pitch : N;
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);   // tile counters: 2 = rows, 3..6 = the column passes
+        const pbh_plan* cp = p;
         if (P > 1) {
             MixParams a = role_a(src, splane, work, N, 0, N, 0);
             a.counter = ctr + 3;
@@ -889,6 +949,9 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colmix<-1>(b, st); }});
         }
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S * N1, N1, p->npol, 0, ctr + 2};
+        if (p->rowmix) {
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowmix(cp, work, st); }});
+        } else
 #ifndef PBH_F64
         if (p->has_phase && row_phase_enabled()) {
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)N), ctr + 2};
@@ -1454,14 +1517,16 @@ static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
 }
 
 // stage radices, W_L table and output permutation of a mixed-radix column transform of length L (mixed_kernels.hpp)
-static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t) {
+// rows: the table of a k_rowmix row transform -- plain radices only (its inverse stages mirror the forward ones one by
+// one), and `perm` holds the INVERSE map, position -> bin: the order the chirp rows are stored in
+static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows = false) {
     t->L = L;
     t->nstage = 0;
     int left = L;
     // radix 9 = 3 x 3 in registers: two levels per LDS round trip (PBH_MIX_SQUARE=0: radix 3 only, for A/B runs).  The same
     // for 25 = 5 x 5 needs more registers than two workgroups per CU leave (230-400 B/lane of scratch): not built.
     static const bool square = [] { const char* e = getenv("PBH_MIX_SQUARE"); return e ? atoi(e) != 0 : true; }();
-    if (square) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
+    if (square && !rows) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
     for (int r : {7, 5, 3}) while (left % r == 0) { if (t->nstage >= kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "too many stages"); t->radix[t->nstage++] = r; left /= r; }
     while (left % 8 == 0) { t->radix[t->nstage++] = 8; left /= 8; }
     while (left % 4 == 0) { t->radix[t->nstage++] = 4; left /= 4; }
@@ -1483,6 +1548,11 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t) {
             rest /= r;
         }
         perm[k] = (unsigned short)pos;
+    }
+    if (rows) {
+        std::vector<unsigned short> inv(L);
+        for (int k = 0; k < L; ++k) inv[perm[k]] = (unsigned short)k;
+        perm = inv;
     }
     int rc;
     if ((rc = dev_alloc(p, (void**)&t->wl, sizeof(cf) * L)) != PBH_OK) return rc;
@@ -1713,6 +1783,12 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = mN2;
         p->P = mP;
         p->mixed = true;
+    } else if (!pow2 && plain_fft == 0 && rowmix_geometry(nsample, &mN1, &mN2, &mP)) {
+        p->N1 = mN1;
+        p->N2 = mN2;
+        p->P = mP;
+        p->mixed = true;
+        p->rowmix = true;
     } else if (!pow2) {
         p->N1 = 1;  // natural-order chirp H/N; the transforms run in a native-length convolution plan
         p->N2 = (int)nsample;
@@ -1800,6 +1876,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
     if (p->mixed) {
         if (p->P > 1 && (rc = build_mix_table(p, p->P, &p->mixP)) != PBH_OK) return bail(rc);
         if ((rc = build_mix_table(p, p->N1 / p->P, &p->mixQ)) != PBH_OK) return bail(rc);
+        if (p->rowmix && (rc = build_mix_table(p, p->N2, &p->mixR, true)) != PBH_OK) return bail(rc);
     }
     *out = p;
     return PBH_OK;
@@ -1812,7 +1889,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) hipFree(p->cf_in);
     void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
-                    p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm};
+                    p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm, p->mixR.wl, p->mixR.perm};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete p;
@@ -1879,10 +1956,11 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     ChirpParams cp{p->chirp, p->chan_freq, coeff_hz, 1.0 / ((double)p->N * dt_s), 1.0 / ref_freq_hz,
                    p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
     cp.P = p->P;
+    cp.row_perm = p->rowmix ? p->mixR.perm : nullptr;
     p->has_phase = false;
 #ifndef PBH_F64
     // the fused row pass of multi-pass float32 plans reads the chirp as a phase (k_rowp)
-    if (p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
+    if (p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL && !p->rowmix) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
         cp.phase16 = rowp16_on(p->N2) ? 1 : 0;
@@ -1919,10 +1997,12 @@ int pbh_chirp_upload_as(pbh_plan* p, const void* chirp_c64, int chirp_dtype, int
     }
     if (chirp_dtype == PBH_C128)
         hipLaunchKernelGGL(k_chirp_reorder<double2>, dim3(2048), dim3(256), 0, p->stream, (const double2*)src, (double2*)nullptr,
-                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
+                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P,
+                           p->rowmix ? p->mixR.perm : (const unsigned short*)nullptr);
     else
         hipLaunchKernelGGL(k_chirp_reorder<float2>, dim3(2048), dim3(256), 0, p->stream, (const float2*)src, (float2*)nullptr,
-                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P);
+                           (const cf*)nullptr, p->chirp, p->N, p->N1, p->N2, p->nchan, inv_n(p), 1, p->perm_w, p->P,
+                           p->rowmix ? p->mixR.perm : (const unsigned short*)nullptr);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
@@ -1942,7 +2022,8 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
         dst = (float2*)p->stage_out;
     }
     hipLaunchKernelGGL(k_chirp_reorder<float2>, dim3(2048), dim3(256), 0, p->stream, (const float2*)nullptr, dst,
-                       (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w, p->P);
+                       (const cf*)p->chirp, (cf*)nullptr, p->N, p->N1, p->N2, p->nchan, (real)p->N, 0, p->perm_w, p->P,
+                       p->rowmix ? p->mixR.perm : (const unsigned short*)nullptr);
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) {
         HIPCHECK(xfer_d2h(chirp_c64, dst, bytes, p->stream));
@@ -1959,10 +2040,11 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipMemcpyAsync(p->chan_freq, arg, sizeof(double) * p->nchan, hipMemcpyHostToDevice, p->stream));
     ChirpParams cp{p->chirp, p->chan_freq, 0.0, 0.0, 0.0, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
     cp.P = p->P;
+    cp.row_perm = p->rowmix ? p->mixR.perm : nullptr;
     bool phase = false;
 #ifndef PBH_F64
     // the time-shift ramp has unit magnitude: the row pass can read it as a phase, like a generated chirp
-    if (mode == 0 && p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL) {
+    if (mode == 0 && p->N1 > 1 && rowp_ok(p->N1, p->N2) && p->perm_w == 0 && !p->bsL && !p->rowmix) {
         if (!p->chirp_phase) PBHCHECK(dev_alloc(p, (void**)&p->chirp_phase, sizeof(float) * (size_t)p->nchan * p->N));
         cp.phase = p->chirp_phase;
         cp.phase16 = rowp16_on(p->N2) ? 1 : 0;

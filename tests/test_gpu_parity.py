@@ -1086,3 +1086,46 @@ def test_fft_7smooth_lengths(n, tail, dtype):
     rng = np.random.default_rng(n % 1000 + len(tail))
     x = (rng.standard_normal((n,) + tail) + 1j * rng.standard_normal((n,) + tail)).astype(dtype)
     _fft_check(x, 2e-6 if dtype == np.complex64 else 1e-12)
+
+
+# 7-smooth lengths with only three or four factors of two: no power-of-two rows, the rows are mixed-radix as well (k_rowmix)
+ROWMIX = [
+    (81000, 81, 1000),            # 2^3 3^4 5^3: rows of 8 x 125 points
+    (176400, 175, 1008),          # 2^4 3^2 5^2 7^2: rows of 16 x 63
+    (437400, 675, 648),           # 2^3 3^7 5^2
+    (8 * 3 * 5 * 7 * 11 // 11 * 9, 9, 840),   # 7560 = 2^3 3^3 5 7: short everything
+    (8505000, 8505, 1000),        # 2^3 3^5 5^4 7: two column levels
+]
+
+
+@pytest.mark.parametrize("n,n1,n2", ROWMIX)
+@pytest.mark.parametrize("tail", [(1,), (3, 2), (4, 2)])
+def test_7smooth_few_factors_of_two(n, n1, n2, tail):
+    from pulsarbat_amd import _hip
+    info = _hip.Plan(n, 1, 1, 0, n, device=0).info
+    assert (info["n1"], info["n2"]) == (n1, n2), info
+    if n * int(np.prod(tail)) > 1 << 25:
+        pytest.skip("oracle time")
+    for device in (False, True):
+        check((n,) + tail, 3.0, 1e6, 1e9, seed=n % 97, device=device)
+    if tail == (3, 2):
+        check128((n,) + tail, 3.0)
+
+
+def test_7smooth_few_factors_user_chirp_and_shift():
+    """user chirps go through the plan-order upload (rows in k_rowmix's digit-reversed order), time_shift through
+    pbh_chirp_special"""
+    n, tail = 81000, (3, 2)
+    x = orc.synthetic_block((n,) + tail, 6)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    c = np.exp(2j * np.pi * np.random.default_rng(1).random((n, tail[0]))).astype(np.complex64)
+    yc = pb.coherent_dedispersion(z, pb.DM(4.0), chirp=c)
+    _, start, stop = orc.coherent_dedispersion(x, 4.0, 1e6, 1e9)
+    import scipy.fft
+    ref = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * c[:, :, None], axis=0)[start:stop]
+    assert series_errors(np.asarray(yc), ref)[0] < RTOL_L2
+    ch = pb.DM(4.0).chirp_from_signal(z)
+    want = orc.chirp_from_signal(4.0, (n,) + tail, 1e6, 1e9)
+    assert np.abs(np.asarray(ch) - want).max() < 2e-6
+    ys = pb.time_shift(z, 2.5)
+    assert series_errors(np.asarray(ys), orc.time_shift(x, 2.5)[0])[0] < RTOL_L2
