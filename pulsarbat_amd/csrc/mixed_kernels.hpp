@@ -421,41 +421,69 @@ __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
         }
         srad[tid] = r;
     }
-    const int64_t ntile = (p.nrows + FR - 1) / FR;
-    const int tile_elems = FR * N2;
-    const float inv_n2 = 1.0f / (float)N2;
-    for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const int64_t g0 = t * FR;
-        const int rows = (int)(p.nrows - g0 < FR ? p.nrows - g0 : FR);
-        const int cnt = rows * N2;
-        cf* src = p.data + g0 * N2;
-        // this tile's samples and its chirp values (consumed after the forward stages)
-        cf v[NI], c[NI];
+    // a tile is FR consecutive rows of ONE series (the last tile of a series is short): its chirp values are then one
+    // contiguous run too, read with the same flat index as the samples
+    const int64_t tps = (p.N1 + FR - 1) / FR, ntile = (p.nrows / p.N1) * tps;
+    auto tile_geom = [&](int64_t t, int64_t& dbase, int64_t& cbase) -> int {
+        const int64_t srs = t / tps, r0 = (t - srs * tps) * FR;
+        dbase = (srs * p.N1 + r0) * N2;
+        cbase = ((srs / p.npol) * p.N1 + r0) * N2;
+        const int64_t left = p.N1 - r0;
+        return (int)(left < FR ? left : FR);
+    };
+    int64_t t = blockIdx.x;
+    if (t >= ntile) return;
+    cf v[NI];
+    {
+        int64_t db, cb;
+        const int cnt = tile_geom(t, db, cb) * N2;
+        const cf* src = p.data + db;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int e = tid + NT * i;
-            if (e < cnt) {
-                v[i] = src[e];
-                const int row = (int)(((float)e + 0.5f) * inv_n2);          // exact: e < 2^13
-                const int64_t g = g0 + row, srs = g / p.N1, r = g - srs * p.N1;
-                c[i] = p.chirp[((srs / p.npol) * p.N1 + r) * (int64_t)N2 + (e - row * N2)];
-            }
+            v[i] = src[e < cnt ? e : cnt - 1];   // (clamped, not predicated: no branches around the loads)
         }
+    }
+    while (true) {
+        int64_t db, cb;
+        const int rows = tile_geom(t, db, cb), cnt = rows * N2;
+        cf* dst = p.data + db;
         __syncthreads();   // the previous tile's stores have read LDS
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int e = tid + NT * i;
             if (e < cnt) lds[e] = v[i];
         }
+        const int64_t tn = t + gridDim.x;
+        if (tn < ntile) {   // the next tile's samples travel while this one is transformed
+            int64_t db2, cb2;
+            const int cn = tile_geom(tn, db2, cb2) * N2;
+            const cf* src = p.data + db2;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = tid + NT * i;
+                v[i] = src[e < cn ? e : cn - 1];
+            }
+        }
         __syncthreads();
         for (int j = 0; j < p.nstage; ++j) {
             rowmix_stage_r<false>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
             __syncthreads();
         }
+        {
+            // the chirp in the rows' digit-reversed order: element by element (a batch of loads, then the products)
+            const cf* csrc = p.chirp + cb;
+            cf c[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = tid + NT * i;
-            if (e < cnt) lds[e] = cmul(lds[e], c[i]);
+            for (int i = 0; i < NI; ++i) {
+                const int e = tid + NT * i;
+                c[i] = csrc[e < cnt ? e : cnt - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = tid + NT * i;
+                if (e < cnt) lds[e] = cmul(lds[e], c[i]);
+            }
         }
         __syncthreads();
         for (int j = p.nstage - 1; j >= 0; --j) {
@@ -465,10 +493,11 @@ __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int e = tid + NT * i;
-            if (e < cnt) src[e] = lds[e];
+            if (e < cnt) dst[e] = lds[e];
         }
+        if (tn >= ntile) break;
+        t = tn;
     }
-    (void)tile_elems;
 }
 
 }  // namespace PBH_NS

@@ -1089,21 +1089,21 @@ def test_fft_7smooth_lengths(n, tail, dtype):
 
 
 # 7-smooth lengths with only three or four factors of two: no power-of-two rows, the rows are mixed-radix as well (k_rowmix)
-ROWMIX = [
-    (81000, 81, 1000),            # 2^3 3^4 5^3: rows of 8 x 125 points
-    (176400, 175, 1008),          # 2^4 3^2 5^2 7^2: rows of 16 x 63
-    (437400, 675, 648),           # 2^3 3^7 5^2
-    (8 * 3 * 5 * 7 * 11 // 11 * 9, 9, 840),   # 7560 = 2^3 3^3 5 7: short everything
-    (8505000, 8505, 1000),        # 2^3 3^5 5^4 7: two column levels
-]
+ROWMIX = [81000,        # 2^3 3^4 5^3
+          176400,       # 2^4 3^2 5^2 7^2
+          437400,       # 2^3 3^7 5^2
+          7560,         # 2^3 3^3 5 7: short everything
+          8505000]      # 2^3 3^5 5^4 7: two column levels
 
 
-@pytest.mark.parametrize("n,n1,n2", ROWMIX)
+@pytest.mark.parametrize("n", ROWMIX)
 @pytest.mark.parametrize("tail", [(1,), (3, 2), (4, 2)])
-def test_7smooth_few_factors_of_two(n, n1, n2, tail):
+def test_7smooth_few_factors_of_two(n, tail):
     from pulsarbat_amd import _hip
     info = _hip.Plan(n, 1, 1, 0, n, device=0).info
-    assert (info["n1"], info["n2"]) == (n1, n2), info
+    n1, n2 = info["n1"], info["n2"]
+    # a real split with mixed-radix rows: N2 = 8 or 16 times an odd factor, not the (1, n) of a convolution plan
+    assert n1 * n2 == n and n1 > 1 and n2 % 8 == 0 and n2 & (n2 - 1) and n2 <= 1024, info
     if n * int(np.prod(tail)) > 1 << 25:
         pytest.skip("oracle time")
     for device in (False, True):
