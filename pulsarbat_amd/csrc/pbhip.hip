@@ -153,9 +153,10 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     return true;
 }
 
-// 7-smooth lengths with only three or four factors of two: no power-of-two rows of 32 points, so the rows are mixed-radix too
+// 7-smooth lengths with one to four factors of two: no power-of-two rows of 32 points, so the rows are mixed-radix too
 // (k_rowmix): N2 = 2^k * f, f odd, at most 1024 points, as long as possible such that N1 = N / N2 still splits into column
-// levels of at most 1024 rows.  The column passes then work on pieces of 2^k elements (64 or 128 bytes).  PBH_ROWMIX=0: off.
+// levels of at most 1024 rows.  The column passes take pieces of up to 512 elements of a row, the last one of a row short
+// (rows start at multiples of 2^k elements: 16 to 128 bytes).  PBH_ROWMIX=0: off.
 static bool split_levels(int64_t n1, int64_t* qout) {
     int64_t q = 0;
     if (n1 <= kMixMaxLen) q = n1;
@@ -174,7 +175,8 @@ static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
     if (!on || mode < 2 || n < 4096 || is_pow2(n) || !is_7smooth(n)) return false;
     int k = 0;
     while (((n >> k) & 1) == 0) ++k;
-    if (k < 3) return false;
+    static const int kmin = [] { const char* e = getenv("PBH_ROWMIX_KMIN"); return e ? atoi(e) : 1; }();
+    if (k < kmin) return false;   // (odd lengths: planar rows would start at odd element offsets -- left to the convolution plan)
     if (k > 4) k = 4;
     // the longest row that leaves a splittable N1 (measured on 10 935 000 x 16: rows of 1000 points 5.03 ms, 600: 5.06,
     // 360: 5.28, 200: 5.29, 72: 5.26 -- the row pass gets slower with its stage count, the column levels faster)
@@ -190,6 +192,15 @@ static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
         return true;
     }
     return false;
+}
+
+// The seven passes of a plan with mixed-radix rows cost about what a convolution plan of length 2.0 N costs (0.47 ms per 2^20
+// samples x 16 series against 0.238 ms per 2^20 samples of the padded length, profiles/r02_7smooth.txt): the convolution
+// stays when 2N - 1 lands just below a native length.  PBH_ROWMIX=2: always the mixed-radix rows.
+static bool rowmix_pays(int64_t n) {
+    static const int mode = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) : 1; }();
+    if (mode >= 2) return true;
+    return (double)convolution_length(2 * n - 1) / (double)n >= 2.06;
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
@@ -1785,7 +1796,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = mN2;
         p->P = mP;
         p->mixed = true;
-    } else if (!pow2 && plain_fft == 0 && rowmix_geometry(nsample, &mN1, &mN2, &mP)) {
+    } else if (!pow2 && plain_fft == 0 && rowmix_geometry(nsample, &mN1, &mN2, &mP) && rowmix_pays(nsample)) {
         p->N1 = mN1;
         p->N2 = mN2;
         p->P = mP;

@@ -38,12 +38,12 @@ _SMOOTH = None
 
 
 def smooth_len(lo, hi):
-    """A 7-smooth multiple of 32 in [lo, hi] that is not a power of two: the mixed-radix column pass (both of its levels
-    when the process runs with PBH_MIXED=2)."""
+    """An even 7-smooth number in [lo, hi] that is not a power of two: the mixed-radix column passes (one or two levels)
+    and, with fewer than five factors of two, the mixed-radix rows."""
     global _SMOOTH
     if _SMOOTH is None:
         from pulsarbat_amd.utils import _smooth_7
-        _SMOOTH = [v for v in _smooth_7(1 << 22) if v % 32 == 0 and v & (v - 1)]
+        _SMOOTH = [v for v in _smooth_7(1 << 22) if v % 2 == 0 and v & (v - 1)]
     return int(rng.choice([v for v in _SMOOTH if lo <= v <= hi]))
 
 
