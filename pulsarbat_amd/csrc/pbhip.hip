@@ -153,7 +153,7 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     return true;
 }
 
-// 7-smooth lengths with one to four factors of two: no power-of-two rows of 32 points, so the rows are mixed-radix too
+// 7-smooth lengths with at most four factors of two: no power-of-two rows of 32 points, so the rows are mixed-radix too
 // (k_rowmix): N2 = 2^k * f, f odd, at most 1024 points, as long as possible such that N1 = N / N2 still splits into column
 // levels of at most 1024 rows.  The column passes take pieces of up to 512 elements of a row, the last one of a row short
 // (rows start at multiples of 2^k elements: 16 to 128 bytes).  PBH_ROWMIX=0: off.
@@ -175,8 +175,10 @@ static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
     if (!on || mode < 2 || n < 4096 || is_pow2(n) || !is_7smooth(n)) return false;
     int k = 0;
     while (((n >> k) & 1) == 0) ++k;
-    static const int kmin = [] { const char* e = getenv("PBH_ROWMIX_KMIN"); return e ? atoi(e) : 1; }();
-    if (k < kmin) return false;   // (odd lengths: planar rows would start at odd element offsets -- left to the convolution plan)
+    // (odd lengths too: their planar rows start at odd element offsets, which costs the layout kernels unaligned 16-byte
+    //  accesses and nothing else; PBH_ROWMIX_KMIN=1 leaves them to the convolution plan)
+    static const int kmin = [] { const char* e = getenv("PBH_ROWMIX_KMIN"); return e ? atoi(e) : 0; }();
+    if (k < kmin) return false;
     if (k > 4) k = 4;
     // the longest row that leaves a splittable N1 (measured on 10 935 000 x 16: rows of 1000 points 5.03 ms, 600: 5.06,
     // 360: 5.28, 200: 5.29, 72: 5.26 -- the row pass gets slower with its stage count, the column levels faster)

@@ -1095,7 +1095,9 @@ ROWMIX = [81000,        # 2^3 3^4 5^3
           7560,         # 2^3 3^3 5 7: short everything
           8505000,      # 2^3 3^5 5^4 7: two column levels
           91125 * 4,    # 2^2 3^6 5^3: rows start at 32-byte offsets
-          2 * 3 ** 5 * 5 ** 3 * 7]   # 2 3^5 5^3 7 = 425250: one factor of two
+          2 * 3 ** 5 * 5 ** 3 * 7,   # 2 3^5 5^3 7 = 425250: one factor of two
+          3 * 5 ** 7,   # 234375, odd: planar rows at odd element offsets
+          3 ** 4 * 5 ** 2 * 7 ** 2]  # 99225, odd
 
 
 @pytest.mark.parametrize("n", ROWMIX)
@@ -1104,8 +1106,8 @@ def test_7smooth_few_factors_of_two(n, tail):
     from pulsarbat_amd import _hip
     info = _hip.Plan(n, 1, 1, 0, n, device=0).info
     n1, n2 = info["n1"], info["n2"]
-    # a real split with mixed-radix rows: N2 = 2..16 times an odd factor, not the (1, n) of a convolution plan
-    assert n1 * n2 == n and n1 > 1 and n2 % 2 == 0 and n2 & (n2 - 1) and n2 <= 1024, info
+    # a real split with mixed-radix rows: N2 = 1..16 times an odd factor, not the (1, n) of a convolution plan
+    assert n1 * n2 == n and n1 > 1 and n2 & (n2 - 1) and n2 <= 1024, info
     if n * int(np.prod(tail)) > 1 << 25:
         pytest.skip("oracle time")
     for device in (False, True):

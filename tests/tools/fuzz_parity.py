@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
         n = int(rng.integers(2000, 400000))
     else:   # 7-smooth: the mixed-radix column pass (one level by default; both levels when run with PBH_MIXED=2)
         from pulsarbat_amd.utils import _smooth_7
-        cand = [v for v in _smooth_7(1 << 21) if v >= 2000 and v % 2 == 0 and v & (v - 1)]   # (even: also the plans with mixed-radix rows)
+        cand = [v for v in _smooth_7(1 << 21) if v >= 2000 and v & (v - 1)]   # (odd ones too: the plans with mixed-radix rows)
         n = int(rng.choice(cand))
     nchan = int(rng.integers(1, 10))
     npol = int(rng.choice([1, 2]))

@@ -43,7 +43,7 @@ def smooth_len(lo, hi):
     global _SMOOTH
     if _SMOOTH is None:
         from pulsarbat_amd.utils import _smooth_7
-        _SMOOTH = [v for v in _smooth_7(1 << 22) if v % 2 == 0 and v & (v - 1)]
+        _SMOOTH = [v for v in _smooth_7(1 << 22) if v & (v - 1)]
     return int(rng.choice([v for v in _SMOOTH if lo <= v <= hi]))
 
 
