@@ -245,8 +245,10 @@ __global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf
 // which turns the forward transform into the unnormalised-inverse-times-scale (ifft with scale = 1/N).
 // 16-byte stores when B is a multiple of the elements per 16 bytes, 8-byte stores otherwise.
 template <int SB, int TB>
+// (row_perm: rows transformed by k_rowmix hold bin row_perm[position] at each position -- see row_bin)
 __global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* __restrict__ out, int N1, int N2, int B,
-                                                 int P, int inverse, real scale) {
+                                                 int P, int inverse, real scale,
+                                                 const unsigned short* __restrict__ row_perm = nullptr) {
     constexpr int VE = 16 / (int)sizeof(cf);
     constexpr int LD = TB + 1;
     constexpr int NE = SB * TB / 256, NV = SB * TB / VE / 256;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* 
                 const cf a = lds[sl * LD + t];
                 const int64_t k1 = col / B;
                 const int s = (int)(col - k1 * B);
-                int64_t k = k1 + (int64_t)N1 * (k20 + t);
+                int64_t k = k1 + (int64_t)N1 * (row_perm ? (int64_t)row_perm[k20 + t] : k20 + t);
                 if (inverse) k = k ? N - k : 0;
                 out[k * B + s] = make_cf(a.x * scale, a.y * scale);
             }
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fft_out(const cf* __restrict__ in, cf* 
             }
             const int64_t k1 = col / B;
             const int s = (int)(col - k1 * B);
-            int64_t k = k1 + (int64_t)N1 * (k20 + t);
+            int64_t k = k1 + (int64_t)N1 * (row_perm ? (int64_t)row_perm[k20 + t] : k20 + t);
             if (inverse) k = k ? N - k : 0;
             *reinterpret_cast<vec16*>(out + k * B + s) = x.v;   // B % VE == 0: the VE elements share one k
         }

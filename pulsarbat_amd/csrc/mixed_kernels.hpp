@@ -401,6 +401,9 @@ __device__ __forceinline__ void rowmix_stage_r(int r, cf* lds, const cf* wl, int
     }
 }
 
+// FWD_ONLY: the forward stages alone (stand-alone transforms, pbh_fft_c2c): the rows stay in digit-reversed order, which the
+// output pass undoes (k_fft_out, row_perm)
+template <bool FWD_ONLY>
 __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
     constexpr int NT = 512;
     constexpr int NI = kMixTileBytes / (int)sizeof(cf) / NT;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
             rowmix_stage_r<false>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
             __syncthreads();
         }
-        {
+        if constexpr (!FWD_ONLY) {
             // the chirp in the rows' digit-reversed order: element by element (a batch of loads, then the products)
             const cf* csrc = p.chirp + cb;
             cf c[NI];
@@ -485,10 +488,12 @@ __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
                 if (e < cnt) lds[e] = cmul(lds[e], c[i]);
             }
         }
-        __syncthreads();
-        for (int j = p.nstage - 1; j >= 0; --j) {
-            rowmix_stage_r<true>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
+        if constexpr (!FWD_ONLY) {
             __syncthreads();
+            for (int j = p.nstage - 1; j >= 0; --j) {
+                rowmix_stage_r<true>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {

@@ -752,7 +752,7 @@ static int launch_colmix(const MixParams& prm, hipStream_t st) {
     return launch_tile_kernel(k_colmix<DIR>, q, tiles, 512, st, (int)lds);
 }
 
-static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st) {
+static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st, bool fwd_only = false) {
     RowMixParams r{};
     r.data = work;
     r.chirp = p->chirp;
@@ -765,7 +765,8 @@ static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st) {
     const size_t lds = ((size_t)r.FR * p->N2 + p->N2) * sizeof(cf) + 2 * kMixMaxStages * sizeof(int) + 16;
     int64_t tiles = (int64_t)p->S * ((p->N1 + r.FR - 1) / r.FR);   // tiles do not straddle series
     if (tiles > 2048) tiles = 2048;
-    return launch_tile_kernel(k_rowmix, r, tiles, 512, st, (int)lds);
+    return fwd_only ? launch_tile_kernel(k_rowmix<true>, r, tiles, 512, st, (int)lds)
+                    : launch_tile_kernel(k_rowmix<false>, r, tiles, 512, st, (int)lds);
 }
 
 // k_colmix parameters of a mixed plan's two column roles (mixed_kernels.hpp): A = the P-point stage over rows one chunk
@@ -1798,7 +1799,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = mN2;
         p->P = mP;
         p->mixed = true;
-    } else if (!pow2 && plain_fft == 0 && rowmix_geometry(nsample, &mN1, &mN2, &mP) && rowmix_pays(nsample)) {
+    } else if (!pow2 && plain_fft != 1 && rowmix_geometry(nsample, &mN1, &mN2, &mP) && (plain_fft == 2 || rowmix_pays(nsample))) {
         p->N1 = mN1;
         p->N2 = mN2;
         p->P = mP;
@@ -2852,8 +2853,9 @@ static bool native_fft_ok(int64_t n, int64_t batch) {
     static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
     if (!on || batch > 65535 || n <= kTilePoints || n > (1LL << 28)) return false;
     if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
-    int n1, n2, pp;   // 7-smooth lengths with rows the stand-alone row transform has (mixed_kernels.hpp)
-    return mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024;
+    int n1, n2, pp;   // 7-smooth lengths with rows the stand-alone row transform has, or with mixed-radix rows (mixed_kernels.hpp)
+    if (mixed_geometry(n, &n1, &n2, &pp)) return n2 >= 1024;
+    return rowmix_geometry(n, &n1, &n2, &pp);
 }
 
 // Forward transforms of a native-length plan `p` (batch = p->S series of p->N samples) up to plan order in p->work.
@@ -2880,6 +2882,7 @@ static int native_forward(pbh_plan* p, const cf* din, int il, hipStream_t st) {
         MixParams b = mix_role_b(p, src, n, work, n, 0, n, 0);
         b.counter = ctr + 4;
         PBHCHECK(launch_colmix<-1>(b, st));
+        if (p->rowmix) return launch_rowmix(p, work, st, true);   // rows left in digit-reversed order (k_fft_out undoes it)
         return launch_rowfft(N2, work, p->tw16k, (int64_t)S * N1, st);
     }
     BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, n - 1};
@@ -2919,7 +2922,8 @@ static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, i
     constexpr int SB = 64, TB = kBlkElems / 64;
     const int64_t ncol = (int64_t)p->N1 * p->S;
     hipLaunchKernelGGL((k_fft_out<SB, TB>), dim3((unsigned)((ncol + SB - 1) / SB), (unsigned)((p->N2 + TB - 1) / TB)), dim3(256), 0, st,
-                       (const cf*)p->work, dout, p->N1, p->N2, p->S, p->P, inverse, inverse ? (real)(1.0 / (double)n) : (real)1);
+                       (const cf*)p->work, dout, p->N1, p->N2, p->S, p->P, inverse, inverse ? (real)(1.0 / (double)n) : (real)1,
+                       p->rowmix ? p->mixR.perm : (const unsigned short*)nullptr);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }

@@ -1079,6 +1079,8 @@ def test_native_length_list_matches_the_plans():
     (75 << 14, (2,), np.complex64), (81 << 12, (3,), np.complex64), (35 << 11, (2, 2), np.complex64),
     (625 << 10, (1,), np.complex64), (45 << 13, (2,), np.complex128),
     (2025 << 10, (2,), np.complex64), (3125 << 10, (1,), np.complex128),   # N1 = P x Q: both column levels
+    (81000, (2,), np.complex64), (437400, (3,), np.complex64), (234375, (2,), np.complex64), (99225, (2,), np.complex128),
+    (8505000, (1,), np.complex64),   # few factors of two / odd: mixed-radix rows, undone by the output pass
 ])
 def test_fft_7smooth_lengths(n, tail, dtype):
     """pb.fft.fft / ifft of 7-smooth lengths q * 2^k (q <= 1024, 2^k >= 1024): mixed-radix column pass + the engine's row
