@@ -355,7 +355,7 @@ struct RowMixParams {
     int N1, npol, N2;
     int FR;              // rows per tile: FR * N2 <= the tile budget
     int nstage;
-    int radix[kMixMaxStages];   // forward order; radices 7, 5, 3, 8, 4, 2
+    int radix[kMixMaxStages];   // forward order; radices 9, 7, 5, 3, 8, 4, 2
     const cf* wl;        // W_N2^p
 };
 
@@ -380,12 +380,16 @@ __device__ __forceinline__ void rowmix_stage(cf* lds, const cf* wl, int N2, int 
         }
         if (INV) MixDft<R, +1>::run(v, wl, N2);
         else MixDft<R, -1>::run(v, wl, N2);
+        // (register position q2 holds output index out_index(q2): the composite radix 9 leaves its outputs transposed)
         if (!INV && m > 1) {
 #pragma unroll
-            for (int u = 1; u < R; ++u) v[u] = cmul(v[u], wl[iw * u]);
+            for (int q2 = 1; q2 < R; ++q2) {
+                const int u = MixDft<R, -1>::out_index(q2);
+                if (u != 0) v[q2] = cmul(v[q2], wl[iw * u]);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < R; ++u) base[u * m] = v[u];
+        for (int q2 = 0; q2 < R; ++q2) base[MixDft<R, -1>::out_index(q2) * m] = v[q2];
     }
 }
 template <bool INV>
@@ -397,6 +401,7 @@ __device__ __forceinline__ void rowmix_stage_r(int r, cf* lds, const cf* wl, int
         case 5: rowmix_stage<5, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
         case 7: rowmix_stage<7, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
         case 8: rowmix_stage<8, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
+        case 9: rowmix_stage<9, INV>(lds, wl, N2, Lj, rows, tid, nthreads); break;
         default: break;
     }
 }

@@ -1533,8 +1533,8 @@ static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
 }
 
 // stage radices, W_L table and output permutation of a mixed-radix column transform of length L (mixed_kernels.hpp)
-// rows: the table of a k_rowmix row transform -- plain radices only (its inverse stages mirror the forward ones one by
-// one), and `perm` holds the INVERSE map, position -> bin: the order the chirp rows are stored in
+// rows: the table of a k_rowmix row transform: `perm` holds the INVERSE map, position -> bin -- the order the chirp rows are
+// stored in (its inverse stages mirror the forward ones one by one)
 static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows = false) {
     t->L = L;
     t->nstage = 0;
@@ -1542,7 +1542,7 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows 
     // radix 9 = 3 x 3 in registers: two levels per LDS round trip (PBH_MIX_SQUARE=0: radix 3 only, for A/B runs).  The same
     // for 25 = 5 x 5 needs more registers than two workgroups per CU leave (230-400 B/lane of scratch): not built.
     static const bool square = [] { const char* e = getenv("PBH_MIX_SQUARE"); return e ? atoi(e) != 0 : true; }();
-    if (square && !rows) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
+    if (square) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
     for (int r : {7, 5, 3}) while (left % r == 0) { if (t->nstage >= kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "too many stages"); t->radix[t->nstage++] = r; left /= r; }
     while (left % 8 == 0) { t->radix[t->nstage++] = 8; left /= 8; }
     while (left % 4 == 0) { t->radix[t->nstage++] = 4; left /= 4; }
