@@ -89,7 +89,11 @@ const char* pbh_version(void);
 /* ---- plan ------------------------------------------------------------------------------- */
 /* One plan = one (nsample, nchan, npol) block geometry on one device + its chirp.  crop_start /
  * crop_stop are the reference's start/stop (pulsarbat/transforms/dedispersion.py:130-131); the
- * crop is fused into the last kernel, so only stop-start rows are written.                      */
+ * crop is fused into the last kernel, so only stop-start rows are written.
+ * nsample: any length in [2, 2^28] (powers of two) / [2, 2^27] (others), as scipy.fft accepts any (pulsarbat/fft.py:36-38).
+ * Powers of two, m * 2^k (m = 3, 5, 7) and 7-smooth lengths -- what pulsarbat.utils.next_fast_len / prev_fast_len return
+ * (utils.py:68-130) -- are transformed directly (pbh_plan_info: nsample = n1 * n2); any other length runs one padded
+ * convolution of about twice the length (n1 = 1, n2 = nsample), exact.                                                  */
 int pbh_plan_create(pbh_plan** out, int device, int64_t nsample, int nchan, int npol,
                     int dtype, int64_t crop_start, int64_t crop_stop);
 int pbh_plan_destroy(pbh_plan* plan);
