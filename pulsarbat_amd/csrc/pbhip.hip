@@ -1793,7 +1793,8 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
         p->N2 = kTilePoints;
         p->N1 = (int)(nsample / kTilePoints);
         p->P = odd_m;
-    } else if (!pow2 && plain_fft != 1 && mixed_geometry(nsample, &mN1, &mN2, &mP)) {
+    } else if (!pow2 && plain_fft != 1 && mixed_geometry(nsample, &mN1, &mN2, &mP) && !(plain_fft == 2 && mN2 < 1024)) {
+        // (stand-alone transforms have no row kernel for power-of-two rows under 1024 points: those lengths take mixed-radix rows)
         // 7-smooth: both column roles are mixed-radix transforms in LDS (k_colmix), the rows stay with the 2^k engine
         p->N1 = mN1;
         p->N2 = mN2;
@@ -2854,7 +2855,7 @@ static bool native_fft_ok(int64_t n, int64_t batch) {
     if (!on || batch > 65535 || n <= kTilePoints || n > (1LL << 28)) return false;
     if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
     int n1, n2, pp;   // 7-smooth lengths with rows the stand-alone row transform has, or with mixed-radix rows (mixed_kernels.hpp)
-    if (mixed_geometry(n, &n1, &n2, &pp)) return n2 >= 1024;
+    if (mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024) return true;
     return rowmix_geometry(n, &n1, &n2, &pp);
 }
 

@@ -1081,6 +1081,7 @@ def test_native_length_list_matches_the_plans():
     (2025 << 10, (2,), np.complex64), (3125 << 10, (1,), np.complex128),   # N1 = P x Q: both column levels
     (81000, (2,), np.complex64), (437400, (3,), np.complex64), (234375, (2,), np.complex64), (99225, (2,), np.complex128),
     (8505000, (1,), np.complex64),   # few factors of two / odd: mixed-radix rows, undone by the output pass
+    (400000, (2,), np.complex64), (1000000, (3,), np.complex64),   # 2^7 5^5, 2^6 5^6: short power-of-two rows -> mixed-radix rows
 ])
 def test_fft_7smooth_lengths(n, tail, dtype):
     """pb.fft.fft / ifft of 7-smooth lengths q * 2^k (q <= 1024, 2^k >= 1024): mixed-radix column pass + the engine's row
