@@ -18,7 +18,8 @@ def free():
 
 rng = np.random.default_rng(0)
 def one_round(k):
-    n = [1 << 18, 3 << 19, 100003, 1 << 20, 625 << 7, 2025 << 5][k % 6]   # (the last two: 7-smooth, one and two column levels)
+    n = [1 << 18, 3 << 19, 100003, 1 << 20, 625 << 7, 2025 << 5, 81000, 234375][k % 8]   # (the last four: 7-smooth -- one and two
+                                                                                      #  column levels, mixed-radix rows, odd)
     x = (rng.standard_normal((n, 2, 2)) + 1j * rng.standard_normal((n, 2, 2))).astype(np.complex64)
     z = pb.DualPolarizationSignal(x, sample_rate=1 * u.MHz, center_freq=1 * u.GHz, pol_type="linear").to_device()
     y = pb.coherent_dedispersion(z, pb.DM(2.0))
