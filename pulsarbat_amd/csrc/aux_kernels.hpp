@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams q) {
 //                         the forward one read at index n - t)
 template <int TB>
 __global__ __launch_bounds__(256) void k_stft_out(const cf* __restrict__ in, cf* __restrict__ out, int N1, int N2, int P,
-                                                 int64_t nseg, int nchan, int E, int inverse, real scale) {
+                                                 int64_t nseg, int nchan, int E, int inverse, real scale,
+                                                  const unsigned short* __restrict__ row_perm = nullptr) {
     constexpr int SB = 64, LD = TB + 1, NE = SB * TB / 256;
     __shared__ cf lds[SB * LD];
     __shared__ int64_t src_row[SB];
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(256) void k_stft_out(const cf* __restrict__ in, cf*
         const int64_t k2 = k20 + t;
         if (k2 < N2) {
             const cf a = lds[sl_own * LD + t];
-            const int64_t k = k1 + (int64_t)N1 * k2;
+            const int64_t k = k1 + (int64_t)N1 * (row_perm ? (int64_t)row_perm[k2] : k2);   // (rows of k_rowmix: see row_bin)
             if (!inverse) {
-                const int64_t kk = k + n / 2 < n ? k + n / 2 : k - n / 2;
+                const int64_t kk = k + n / 2 < n ? k + n / 2 : k + n / 2 - n;   // fftshift, odd n too
                 out[dst_base + kk * E] = make_cf(a.x * scale, a.y * scale);
             } else {
                 const int64_t tt = k ? n - k : 0;

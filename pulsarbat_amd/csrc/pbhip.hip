@@ -2951,7 +2951,9 @@ static bool stft_native_ok(int64_t n, int64_t nseg, int64_t S) {
         return false;
     if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
     int n1, n2, pp;
-    return mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024;
+    if (mixed_geometry(n, &n1, &n2, &pp) && n2 >= 1024) return true;
+    // (even lengths only: the inverse pass undoes the fftshift by the sign (-1)^k, which is what it is for even n alone)
+    return n % 2 == 0 && rowmix_geometry(n, &n1, &n2, &pp);
 }
 
 static int stft_native(int device, hipStream_t st, const cf* din, cf* dout, int64_t nseg, int64_t n, int nchan, int inner,
@@ -2966,7 +2968,7 @@ static int stft_native(int device, hipStream_t st, const cf* din, cf* dout, int6
     const int64_t NJ = B * p->N1;
     hipLaunchKernelGGL((k_stft_out<TB>), dim3((unsigned)((NJ + 63) / 64), (unsigned)((p->N2 + TB - 1) / TB)), dim3(256), 0, st,
                        (const cf*)p->work, dout, p->N1, p->N2, p->P, nseg, nchan, inner, inverse,
-                       inverse ? (real)1 : (real)(1.0 / (double)n));
+                       inverse ? (real)1 : (real)(1.0 / (double)n), p->rowmix ? p->mixR.perm : (const unsigned short*)nullptr);
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }

@@ -96,6 +96,7 @@ class TestSTFT:
         (1 << 14, (2, 2), 3, np.complex128), (1 << 16, (1, 2), 2, np.complex128),
         (75 << 10, (2, 2), 3, np.complex64), (45 << 12, (1, 2), 2, np.complex64), (27 << 11, (2,), 3, np.complex128),   # 7-smooth: k_colmix
         (2025 << 10, (2,), 2, np.complex64),   # ... with both column levels (N1 = 3 x 675)
+        (81000, (2, 2), 3, np.complex64), (234375, (1, 2), 2, np.complex64), (400000, (2,), 2, np.complex128),   # mixed-radix rows (k_rowmix)
     ])
     def test_segments_beyond_one_tile(self, n, tail, nseg, dtype):
         """Native segment lengths longer than a tile: the segments are a batch of multi-pass transforms and one
