@@ -1136,3 +1136,10 @@ def test_7smooth_few_factors_user_chirp_and_shift():
     assert np.abs(np.asarray(ch) - want).max() < 2e-6
     ys = pb.time_shift(z, 2.5)
     assert series_errors(np.asarray(ys), orc.time_shift(x, 2.5)[0])[0] < RTOL_L2
+    # odd length: bins and the band mask of freq_shift in natural order through the same plans
+    n = 99225
+    x = orc.synthetic_block((n,) + tail, 7)
+    z = make_signal(x, 1e6, 1e9).to_device()
+    assert series_errors(np.asarray(pb.time_shift(z, -3.25)), orc.time_shift(x, -3.25)[0])[0] < RTOL_L2
+    ft = 0.1371
+    assert series_errors(np.asarray(pb.freq_shift(z, ft * 1e6 * u.Hz)), orc.freq_shift(x, ft))[0] < 2e-5
