@@ -1,27 +1,29 @@
-// mixed_kernels.hpp -- column transforms of 7-smooth length (radices 2, 3, 4, 5, 7) for the lengths that
+// mixed_kernels.hpp -- transforms of 7-smooth length (radices 9, 7, 5, 3, 8, 4, 2) for the lengths that
 // pulsarbat.utils.next_fast_len / prev_fast_len hand out (reference pulsarbat/utils.py:68-130, transforms.py:364-382).
 //
-// A length N = N1 * N2 with N2 = 2^k (the row pass, power-of-two tile engine) and N1 = P * Q any 7-smooth number runs the
-// planar pipeline of pbhip.hip with BOTH column roles played by this one kernel:
+// k_colmix.  A length N = N1 * N2 with N1 = P * Q any 7-smooth number runs the planar pipeline of pbhip.hip with BOTH
+// column roles played by this one kernel:
 //   role A (P > 1, what k_radix_p does for P <= 16): the P-point transform over n1 = Q a + b, rows one chunk = N / P apart,
 //           then the twiddle W_N1^{b c};
 //   role B (what k_colq does for powers of two): the Q-point transform over b inside row block c, then W_N^{n2 k1},
 //           k1 = c + P d.
 // The inverse direction mirrors both (conjugate twiddle first, inverse transform after).
-//
-// One tile = L rows x COLS columns (COLS * sizeof(cf) = 128 bytes: one line per row) in LDS, transformed IN PLACE by
+// One tile = L rows x W columns (W a power of two: as many 8- or 16-byte elements as keep the tile within 64 KiB, at least
+// 64 bytes per row, the last group of a row short when W does not divide the row length) in LDS, transformed IN PLACE by
 // decimation-in-frequency stages of radix r_1, r_2, ... (each: L / r butterflies per column, twiddle W_Lj^{i u} from a W_L table
 // in LDS), which leaves X[k] at the mixed-radix digit-reversed position; the stores read LDS through a permutation table, so
-// rows leave in natural order.  Per-thread float64 recurrence for the inter-pass twiddle as in k_colq.  The pass is bound
-// by HBM like the other column passes as long as the LDS work of its stages (about 1.3 us per stage and tile) stays under
-// the ~12 us a CU has per 256 KiB of traffic; the next tile's samples are requested before the stages of the current one.
+// rows leave in natural order.  Per-thread float64 recurrence for the inter-pass twiddle as in k_colq.  Two workgroups per
+// CU; the next tile's samples are requested before the stages of the current one.
+//
+// k_rowmix (end of the file).  With N2 = 2^k (k >= 5) the rows belong to the power-of-two tile engine (k_row / k_rowp); with
+// fewer factors of two the rows are mixed-radix as well and this kernel is the fused row pass.
 #pragma once
 #include "fft_core.hpp"
 
 namespace PBH_NS {
 
 constexpr int kMixMaxStages = 14;
-constexpr int kMixMaxLen = 1024;   // rows of a tile: 128 KiB of full 128-byte lines in both precisions
+constexpr int kMixMaxLen = 1024;   // rows of a tile at most (64-byte pieces beyond 512 rows of complex64)
 
 struct MixParams {
     const cf* ld;       // loads: series s at s * ld_plane
@@ -34,7 +36,7 @@ struct MixParams {
     int64_t bstride;
     int64_t ncolgrp;    // column groups (W columns each) per block; the last one is short when W does not divide ncols
     int64_t ncols;      // columns of a block (role A: N / P, role B: N2)
-    int wlog2;          // W = 2^wlog2 columns per tile: whole 128-byte lines, L * W <= 2^14 points
+    int wlog2;          // W = 2^wlog2 columns per tile, L * W points within kMixTileBytes
     // twiddle exponent of (row k, column position x): ((x / xdiv) * (c * y0mul + ystep * k) % nmod) * mult, looked up in tw
     int64_t xdiv, ystep, nmod, mult;
     int y0mul;
