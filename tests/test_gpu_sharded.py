@@ -88,6 +88,22 @@ def test_config1_full_size_all_series():
     assert err.shape == (16,) and err.max() < RTOL_L2, f"per-series relative L2: {err}"
 
 
+@pytest.mark.parametrize("n", [625 << 14, 10_000_000, 10_935_000, 13_671_875])
+def test_7smooth_lengths_full_size_all_series(n):
+    """configs[1]'s block at the lengths the reference's fast_len would crop it to (utils.py:68-130): 625 * 2^14 (one
+    mixed-radix column level), 10^7 (two levels), 2^3 3^7 5^4 and the odd 5^9 7 (mixed-radix rows too) -- every one of the
+    16 series against the oracle, same band and DM as the headline."""
+    nchan, npol, sr, fc, dm = 8, 2, 50e6, 1.4e9, 56.77
+    xt = device_block((n, nchan, npol), 20260003 + n % 1000)
+    z = pb.DualPolarizationSignal(pb.DeviceArray(xt), sample_rate=sr * u.Hz, center_freq=fc * u.Hz, pol_type="linear")
+    y = pb.coherent_dedispersion(z, pb.DM(dm))
+    x = xt.cpu().numpy()
+    want, start, stop = orc.coherent_dedispersion(x, dm, sr, fc, workers=NCPU)
+    assert y.shape == want.shape == (stop - start, nchan, npol)
+    err = per_series_l2(y, want)
+    assert err.shape == (16,) and err.max() < RTOL_L2, f"per-series relative L2: {err}"
+
+
 @pytest.mark.parametrize("rank", [0, 5])
 def test_config2_rank_share_full_size(one_rank_group, rank):
     """BASELINE configs[2]: 64 channels of 6.25 MHz over 8 GPUs; this is rank `rank`'s share (8 channels x 2 pol x
