@@ -394,6 +394,46 @@ __device__ __forceinline__ void rowmix_stage(cf* lds, const cf* wl, int N2, int 
         for (int q2 = 0; q2 < R; ++q2) base[MixDft<R, -1>::out_index(q2) * m] = v[q2];
     }
 }
+// The last forward stage, the chirp and the first inverse stage in one round: the last stage's butterflies take R ADJACENT
+// elements and have no twiddles, and the first inverse stage undoes exactly them -- so a thread transforms its R elements
+// forward, multiplies by the chirp values of the same R positions (contiguous in memory: read straight from the chirp row,
+// no staging) and transforms them back.  Two LDS round trips and two barriers less per tile than stage / product / stage.
+template <int R>
+__device__ __forceinline__ void rowmix_mid(cf* lds, const cf* wl, const cf* __restrict__ chirp, int N2, int rows, int tid,
+                                           int nthreads) {
+    const int nbf = rows * (N2 / R);
+    for (int b = tid; b < nbf; b += nthreads) {
+        cf* base = lds + b * R;           // row * N2 + q * R with q < N2 / R: butterfly b starts at element b * R of the tile
+        const cf* cb = chirp + b * R;
+        cf v[R], ch[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) ch[u] = cb[u];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = base[u];
+        MixDft<R, -1>::run(v, wl, N2);
+        cf w[R];
+#pragma unroll
+        for (int q2 = 0; q2 < R; ++q2) {   // register q2 holds output index out_index(q2): back to natural order for the inverse
+            w[MixDft<R, -1>::out_index(q2)] = cmul(v[q2], ch[MixDft<R, -1>::out_index(q2)]);
+        }
+        MixDft<R, +1>::run(w, wl, N2);
+#pragma unroll
+        for (int q2 = 0; q2 < R; ++q2) base[MixDft<R, -1>::out_index(q2)] = w[q2];
+    }
+}
+__device__ __forceinline__ void rowmix_mid_r(int r, cf* lds, const cf* wl, const cf* chirp, int N2, int rows, int tid, int nthreads) {
+    switch (r) {
+        case 2: rowmix_mid<2>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 3: rowmix_mid<3>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 4: rowmix_mid<4>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 5: rowmix_mid<5>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 7: rowmix_mid<7>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 8: rowmix_mid<8>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        case 9: rowmix_mid<9>(lds, wl, chirp, N2, rows, tid, nthreads); break;
+        default: break;
+    }
+}
+
 template <bool INV>
 __device__ __forceinline__ void rowmix_stage_r(int r, cf* lds, const cf* wl, int N2, int Lj, int rows, int tid, int nthreads) {
     switch (r) {
@@ -476,28 +516,16 @@ __global__ __launch_bounds__(512, 4) void k_rowmix(RowMixParams p) {
             }
         }
         __syncthreads();
-        for (int j = 0; j < p.nstage; ++j) {
+        const int nfwd = FWD_ONLY ? p.nstage : p.nstage - 1;
+        for (int j = 0; j < nfwd; ++j) {
             rowmix_stage_r<false>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
             __syncthreads();
         }
         if constexpr (!FWD_ONLY) {
-            // the chirp in the rows' digit-reversed order: element by element (a batch of loads, then the products)
-            const cf* csrc = p.chirp + cb;
-            cf c[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int e = tid + NT * i;
-                c[i] = csrc[e < cnt ? e : cnt - 1];
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int e = tid + NT * i;
-                if (e < cnt) lds[e] = cmul(lds[e], c[i]);
-            }
-        }
-        if constexpr (!FWD_ONLY) {
+            // last forward stage x chirp (stored in the rows' digit-reversed order) x first inverse stage, in one round
+            rowmix_mid_r(srad[p.nstage - 1], lds, wl, p.chirp + cb, N2, rows, tid, NT);
             __syncthreads();
-            for (int j = p.nstage - 1; j >= 0; --j) {
+            for (int j = p.nstage - 2; j >= 0; --j) {
                 rowmix_stage_r<true>(srad[j], lds, wl, N2, slen[j], rows, tid, NT);
                 __syncthreads();
             }

@@ -1548,6 +1548,14 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows 
     while (left % 4 == 0) { t->radix[t->nstage++] = 4; left /= 4; }
     while (left % 2 == 0) { t->radix[t->nstage++] = 2; left /= 2; }
     if (left != 1 || t->nstage > kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "length is not 7-smooth");
+    if (rows && t->nstage > 1) {
+        // k_rowmix runs its LAST forward stage, the chirp and the first inverse stage as one round with the butterfly's
+        // elements, chirp values and outputs all in registers: give that round the smallest radix of the list
+        int best = 0;
+        for (int j = 1; j < t->nstage; ++j)
+            if (t->radix[j] < t->radix[best]) best = j;
+        std::swap(t->radix[best], t->radix[t->nstage - 1]);
+    }
     std::vector<cf> w(L);
     for (int i = 0; i < L; ++i) {
         const double a = -2.0 * M_PI * (double)i / (double)L;
