@@ -196,13 +196,15 @@ static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
     return false;
 }
 
-// The seven passes of a plan with mixed-radix rows cost about what a convolution plan of length 2.0 N costs (0.47 ms per 2^20
-// samples x 16 series against 0.238 ms per 2^20 samples of the padded length, profiles/r02_7smooth.txt): the convolution
-// stays when 2N - 1 lands just below a native length.  PBH_ROWMIX=2: always the mixed-radix rows.
+// The seven passes of a plan with mixed-radix rows cost 0.43 ms per 2^20 samples x 16 series; a convolution plan's three
+// transform passes run on the padded length L and its layout passes on N: it wins when L is a power of two (the fastest
+// plans there are) within 2.2 N (8 268 750: 3.30 against 3.89 ms; 7 873 200: 3.29 / 3.35), and loses with L = m * 2^k
+// (12 301 875: 5.82 / 5.70; 7 144 200: 3.65 / 3.09).  profiles/r02_7smooth.txt.  PBH_ROWMIX=2: always the mixed-radix rows.
 static bool rowmix_pays(int64_t n) {
     static const int mode = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) : 1; }();
     if (mode >= 2) return true;
-    return (double)convolution_length(2 * n - 1) / (double)n >= 2.06;
+    const int64_t L = convolution_length(2 * n - 1);
+    return !is_pow2(L) || (double)L / (double)n >= 2.2;
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------

@@ -1095,7 +1095,7 @@ def test_fft_7smooth_lengths(n, tail, dtype):
 ROWMIX = [81000,        # 2^3 3^4 5^3
           176400,       # 2^4 3^2 5^2 7^2
           437400,       # 2^3 3^7 5^2
-          7560,         # 2^3 3^3 5 7: short everything
+          9000,         # 2^3 3^2 5^3: short everything
           8505000,      # 2^3 3^5 5^4 7: two column levels
           91125 * 4,    # 2^2 3^6 5^3: rows start at 32-byte offsets
           2 * 3 ** 5 * 5 ** 3 * 7,   # 2 3^5 5^3 7 = 425250: one factor of two
