@@ -239,11 +239,22 @@ int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int
 /* Streaming overlap-save over a long HOST-resident block (BASELINE configs[3]): chunks of the plan's
  * nsample rows every hop = crop_stop - crop_start rows; chunk k is one reference call on
  * in[k*hop : k*hop + nsample] (dedispersion.py:81-133) and fills out rows [k*hop, (k+1)*hop) --
- * concatenate() of the chunk results (transforms.py:59-148).  H2D / kernels / D2H are double-buffered
- * on three HIP streams.  in : (total_nsample, nchan, npol) c64 host;  out: (nchunk*hop, nchan, npol) c64
- * host, nchunk = (total_nsample - nsample) / hop + 1 (returned).  ms_total (optional): HIP-event time. */
+ * concatenate() of the chunk results (transforms.py:59-148).  Every input row crosses PCIe once: the rows
+ * consecutive chunks share stay in a device window (the stream's samples exist once,
+ * transforms.py:101-110; readers are offset-addressed, readers/_base.py:298-333).  H2D / kernels / D2H
+ * run on three HIP streams.  in : (total_nsample, nchan, npol) host;  out: (nchunk*hop, nchan, npol)
+ * host, nchunk = (total_nsample - nsample) / hop + 1 (returned).  ms_total (optional): HIP-event time.
+ * Both host ranges are page-locked for the duration of the call; a range that cannot be page-locked (and
+ * is not pinned by the caller already) fails with PBH_ERR_HIP -- there is no pageable-memory fallback.   */
 int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsample, void* host_out,
                           int64_t* nchunk, float* ms_total);
+
+/* Figures of the plan's last streaming call (pbh_dedisperse_stream / _raw); out[i] for i < n:
+ *   0 bytes host -> device   1 bytes device -> host   2 ms the upload stream was busy (first copy .. last)
+ *   3 ms the download stream was busy   4 ms of kernels (sum over chunks, decode and window slides included)
+ *   5 ms total   6 chunks   7 bytes moved device -> device between windows                               */
+#define PBH_STREAM_NSTATS 8
+int pbh_stream_stats(const pbh_plan* plan, double* out, int n);
 
 /* ---- reader-side decode ----------------------------------------------------------------------- */
 /* Replaces the host post-processing of the reference's baseband readers

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_float)]),
+    "pbh_stream_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pbh_dedisperse_stream_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_RawLayout), C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int64),
                                             C.POINTER(C.c_float)]),
@@ -510,6 +511,19 @@ class Plan:
                                            C.c_void_p(out.ctypes.data), C.byref(n), C.byref(ms)))
         assert n.value == nchunk
         return out, float(ms.value)
+
+    def stream_stats(self):
+        """Figures of this plan's last streaming call (``pbh_stream_stats``): bytes over PCIe each way, how long each
+        copy stream was busy, kernel time, total time; GB/s and the overlap efficiency derived from them."""
+        v = (C.c_double * 8)()
+        _check(lib().pbh_stream_stats(self._h, v, 8))
+        d = dict(h2d_bytes=v[0], d2h_bytes=v[1], h2d_ms=v[2], d2h_ms=v[3], kernel_ms=v[4], total_ms=v[5],
+                 nchunk=int(v[6]), d2d_bytes=v[7])
+        d["h2d_GBps"] = v[0] / v[2] / 1e6 if v[2] > 0 else 0.0
+        d["d2h_GBps"] = v[1] / v[3] / 1e6 if v[3] > 0 else 0.0
+        # 1.0 = the call took as long as its slowest stage alone (perfect overlap of upload, kernels and download)
+        d["overlap_efficiency"] = max(v[2], v[3], v[4]) / v[5] if v[5] > 0 else 0.0
+        return d
 
     def dedisperse_stream_raw(self, raw, layout, total_nsample, first=0, conj=None, scale=1.0, out=None):
         """``dedisperse_stream`` fed with raw payload bytes (uint8 numpy array + ``pbh_raw_layout_t`` fields):

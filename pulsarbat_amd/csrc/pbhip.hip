@@ -38,6 +38,7 @@
 #define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
+#define pbh_stream_stats PBH_FN(stream_stats)
 #define pbh_detect PBH_FN(detect)
 #define pbh_fft_c2c PBH_FN(fft_c2c)
 #define pbh_plan_profile PBH_FN(plan_profile)
@@ -268,6 +269,7 @@ struct pbh_plan {
     // is then the chirp's row order (position -> bin)
     bool rowmix = false;
     MixTable mixR;
+    double stream_stats[PBH_STREAM_NSTATS] = {};   // of the last streaming call (pbh_stream_stats)
 };
 
 static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
@@ -3184,107 +3186,211 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
 // hop = stop - start: chunk k covers input rows [k*hop, k*hop + N) and yields output rows
 // [k*hop, (k+1)*hop) -- exactly `concatenate([coherent_dedispersion(z[k*hop : k*hop+N]) for k])` of the
 // reference (each chunk is one reference call; its crop is the valid region of an overlap-save step:
-// dedispersion.py:127-133, transforms.py:59-148).  Two device in/out buffer pairs; H2D, kernels and
-// D2H run on three streams chained by events so chunk k+1 uploads while chunk k computes and chunk
-// k-1 downloads.  Host memory is page-locked for the duration of the call (hipHostRegister).
+// dedispersion.py:127-133, transforms.py:59-148).
+//
+// Every input row crosses PCIe ONCE.  The stream's samples exist once on the host (transforms.py:101-110; readers are
+// offset-addressed, readers/_base.py:298-333) and the N - hop rows two consecutive chunks share stay in HBM: the device
+// holds a WINDOW of N + (B-1)*hop consecutive rows; chunk k of an epoch of B chunks reads rows [j*hop, j*hop + N) of it
+// (j = k mod B) and only the hop rows it adds are uploaded.  Two windows alternate between epochs: the first chunk of an
+// epoch gets the N - hop rows it shares with its predecessor by one device-to-device copy out of the other window's tail
+// (on the compute stream), so uploads never wait for kernels except for the window of two epochs ago.  H2D, kernels and D2H
+// run on three streams chained by events.  Host memory is page-locked for the duration of the call (hipHostRegister); a
+// range that cannot be page-locked and is not pinned already is an error -- pageable memory is never handed to
+// hipMemcpyAsync (see "host <-> device transfers" above).
+namespace {
+struct StreamRig {
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipEvent_t ev_epoch[2] = {nullptr, nullptr};   // window w has been read for the last time (chunks and the slide out of it)
+    hipEvent_t t[6] = {};                          // timing: whole call, H2D stream, D2H stream (first / last)
+    std::vector<hipEvent_t> kev;                   // timing: around every chunk's kernels
+    void* reg[2] = {nullptr, nullptr};             // host ranges registered by this call
+    int rc = PBH_OK;
+    const char* who;
+
+    explicit StreamRig(const char* name) : who(name) {}
+    bool ok(hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(who) + ": " + what + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    }
+    void pin(int slot, void* ptr, size_t bytes) {
+        if (rc != PBH_OK) return;
+        const int r = pin_host_range(ptr, bytes);
+        if (r == 0) reg[slot] = ptr;
+        if (r < 0)
+            rc = fail(PBH_ERR_HIP, std::string(who) + ": the host buffers cannot be page-locked (hipHostRegister failed); "
+                                   "pageable memory is never handed to asynchronous copies");
+    }
+    void create(int64_t nchunk) {
+        if (rc != PBH_OK) return;
+        ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
+        ok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
+        ok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
+        for (int b = 0; b < 2; ++b) {
+            ok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
+            ok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
+            ok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
+            ok(hipEventCreateWithFlags(&ev_epoch[b], hipEventDisableTiming), "hipEventCreate");
+        }
+        for (auto& e : t) ok(hipEventCreate(&e), "hipEventCreate");
+        kev.assign((size_t)(2 * nchunk), nullptr);
+        for (auto& e : kev) ok(hipEventCreate(&e), "hipEventCreate");
+    }
+    // after the last chunk has been enqueued: drain, read the clocks (stats: see pbh_stream_stats in pbhip.h)
+    void finish(double* stats, float* ms_total) {
+        ok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
+        ok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
+        ok(hipEventRecord(t[1], s_out), "hipEventRecord");
+        ok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
+        if (rc != PBH_OK) return;
+        float ms = 0.f;
+        if (ok(hipEventElapsedTime(&ms, t[0], t[1]), "hipEventElapsedTime")) stats[5] = ms;
+        if (ms_total) *ms_total = ms;
+        if (ok(hipEventElapsedTime(&ms, t[2], t[3]), "hipEventElapsedTime")) stats[2] = ms;
+        if (ok(hipEventElapsedTime(&ms, t[4], t[5]), "hipEventElapsedTime")) stats[3] = ms;
+        double kms = 0.0;
+        for (size_t k = 0; k + 1 < kev.size() && rc == PBH_OK; k += 2)
+            if (ok(hipEventElapsedTime(&ms, kev[k], kev[k + 1]), "hipEventElapsedTime")) kms += ms;
+        stats[4] = kms;
+    }
+    ~StreamRig() {
+        for (void* r : reg)
+            if (r) (void)hipHostUnregister(r);
+        for (int b = 0; b < 2; ++b) {
+            if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
+            if (ev_cmp[b]) (void)hipEventDestroy(ev_cmp[b]);
+            if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
+            if (ev_epoch[b]) (void)hipEventDestroy(ev_epoch[b]);
+        }
+        for (auto e : t)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : kev)
+            if (e) (void)hipEventDestroy(e);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_cmp) (void)hipStreamDestroy(s_cmp);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    }
+};
+
+// chunks per epoch: as many as keep a window within `PBH_STREAM_WINDOW_MB` (default 2048 MiB), at most 64, or exactly
+// `PBH_STREAM_EPOCH` (both read per call so that tests can force many short epochs); `step_bytes` = what one more chunk
+// adds to the window
+static size_t stream_window_cap() {
+    const char* e = getenv("PBH_STREAM_WINDOW_MB");
+    return (size_t)(e && atoll(e) > 0 ? atoll(e) : 2048) << 20;
+}
+static int64_t stream_epoch_max() {
+    const char* e = getenv("PBH_STREAM_EPOCH");
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 1 && v <= 64 ? v : 0;   // 0: not forced
+}
+static int64_t stream_epoch_chunks(size_t first_bytes, size_t step_bytes, int64_t nchunk) {
+    const size_t cap = stream_window_cap();
+    int64_t B = 1;
+    if (step_bytes == 0) B = 64;
+    else if (cap > first_bytes) B = 1 + (int64_t)((cap - first_bytes) / step_bytes);
+    B = B > 64 ? 64 : B;
+    if (stream_epoch_max()) B = stream_epoch_max();
+    return B > nchunk ? nchunk : B;
+}
+}  // namespace
+
+int pbh_stream_stats(const pbh_plan* p, double* out, int n) {
+    if (!p || !out || n < 0) return fail(PBH_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n; ++i) out[i] = i < PBH_STREAM_NSTATS ? p->stream_stats[i] : 0.0;
+    return PBH_OK;
+}
+
 int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsample, void* host_out,
                           int64_t* nchunk_out, float* ms_total) {
     if (!p || !host_in || !host_out) return fail(PBH_ERR_INVALID, "NULL argument");
     if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
-    const int64_t hop = p->stop - p->start;
+    const int64_t N = p->N, hop = p->stop - p->start;
     if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
-    if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
-    const int64_t nchunk = (total_nsample - p->N) / hop + 1;
+    if (total_nsample < N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
+    const int64_t nchunk = (total_nsample - N) / hop + 1;
     HIPCHECK(hipSetDevice(p->device));
     const size_t row = sizeof(cf) * (size_t)p->S;
-    const size_t in_bytes = row * (size_t)p->N, out_bytes = row * (size_t)hop;
+    const size_t out_bytes = row * (size_t)hop, step = row * (size_t)hop, keep = row * (size_t)(N - hop);
     const size_t host_in_bytes = row * (size_t)total_nsample, host_out_bytes = out_bytes * (size_t)nchunk;
+    // a chunk starts j*hop rows into its window: the layout kernels want that on a 16-byte boundary, else one chunk per epoch
+    const int64_t B = step % 16 == 0 ? stream_epoch_chunks(row * (size_t)N, step, nchunk) : 1;
+    const size_t win_bytes = row * (size_t)(N + (B - 1) * hop);
+    const int nwin = nchunk > B ? 2 : 1;
 
-    void* din[2] = {nullptr, nullptr};
+    void* dwin[2] = {nullptr, nullptr};
     void* dout[2] = {nullptr, nullptr};
-    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    bool reg_in = false, reg_out = false;
-    int rc = PBH_OK;
-    auto hipok = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-        return e == hipSuccess;
-    };
+    StreamRig rig("pbh_dedisperse_stream");
+    int& rc = rig.rc;
+    double* stats = p->stream_stats;
+    for (int i = 0; i < PBH_STREAM_NSTATS; ++i) stats[i] = 0.0;
     for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
-        if ((rc = dev_alloc(nullptr, &din[b], in_bytes)) != PBH_OK) break;
+        if (b < nwin && (rc = dev_alloc(nullptr, &dwin[b], win_bytes)) != PBH_OK) break;
         rc = dev_alloc(nullptr, &dout[b], out_bytes);
     }
-    if (rc == PBH_OK) {
-        // pinning is best effort: pageable memory still works (copies just stop overlapping)
-        reg_in = hipHostRegister(const_cast<void*>(host_in), host_in_bytes, hipHostRegisterDefault) == hipSuccess;
-        reg_out = hipHostRegister(host_out, host_out_bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
-        hipok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
-        hipok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
-        hipok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
-        for (int b = 0; b < 2; ++b) {
-            hipok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
-            hipok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
-            hipok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
-        }
-        hipok(hipEventCreate(&t0), "hipEventCreate");
-        hipok(hipEventCreate(&t1), "hipEventCreate");
-    }
+    rig.pin(0, const_cast<void*>(host_in), host_in_bytes);
+    rig.pin(1, host_out, host_out_bytes);
+    rig.create(nchunk);
     if (rc == PBH_OK) {
         // the plan's own stream may hold pending work (chirp generation): order after it
-        hipok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
-        hipok(hipEventRecord(t0, s_in), "hipEventRecord");
-        hipok(hipStreamWaitEvent(s_cmp, t0, 0), "hipStreamWaitEvent");
+        rig.ok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
+        rig.ok(hipEventRecord(rig.t[0], rig.s_in), "hipEventRecord");
+        rig.ok(hipEventRecord(rig.t[2], rig.s_in), "hipEventRecord");
+        rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.t[0], 0), "hipStreamWaitEvent");
         for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const int b = (int)(k & 1);
-            const char* src = (const char*)host_in + (size_t)(k * hop) * row;
+            const int64_t e = k / B, j = k - e * B;
+            const int w = (int)(e & 1) % nwin, b = (int)(k & 1);
+            char* win = (char*)dwin[w];
             char* dst = (char*)host_out + (size_t)k * out_bytes;
-            if (k >= 2) hipok(hipStreamWaitEvent(s_in, ev_cmp[b], 0), "hipStreamWaitEvent");  // in[b] consumed
-            hipok(hipMemcpyAsync(din[b], src, in_bytes, hipMemcpyHostToDevice, s_in), "hipMemcpyAsync H2D");
-            hipok(hipEventRecord(ev_in[b], s_in), "hipEventRecord");
-            hipok(hipStreamWaitEvent(s_cmp, ev_in[b], 0), "hipStreamWaitEvent");
-            if (k >= 2) hipok(hipStreamWaitEvent(s_cmp, ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
-            if (rc == PBH_OK) {
-                auto steps = build_steps(p, (const cf*)din[b], (cf*)dout[b]);
-                rc = run_steps(steps, s_cmp);
+            // upload the rows this chunk adds: all N for the first chunk, afterwards rows [(k-1)*hop + N, k*hop + N)
+            if (j == 0 && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
+            const size_t have = k == 0 ? 0 : keep;
+            const size_t add = row * (size_t)N - have;
+            rig.ok(hipMemcpyAsync(win + (size_t)j * step + have, (const char*)host_in + (size_t)k * step + have, add,
+                                  hipMemcpyHostToDevice, rig.s_in), "hipMemcpyAsync H2D");
+            stats[0] += (double)add;
+            rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
+            rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
+            if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
+            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
+            if (j == 0 && k > 0) {   // a new epoch: the shared rows come from the tail of the other window, which is then free
+                if (keep > 0)
+                    rig.ok(hipMemcpyAsync(win, (const char*)dwin[w ^ 1] + (size_t)B * step, keep, hipMemcpyDeviceToDevice, rig.s_cmp),
+                           "hipMemcpyAsync D2D");
+                stats[7] += (double)keep;
+                rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
             }
-            hipok(hipEventRecord(ev_cmp[b], s_cmp), "hipEventRecord");
-            hipok(hipStreamWaitEvent(s_out, ev_cmp[b], 0), "hipStreamWaitEvent");
-            hipok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, s_out), "hipMemcpyAsync D2H");
-            hipok(hipEventRecord(ev_out[b], s_out), "hipEventRecord");
+            if (rc == PBH_OK) {
+                auto steps = build_steps(p, (const cf*)(win + (size_t)j * step), (cf*)dout[b]);
+                rc = run_steps(steps, rig.s_cmp);
+            }
+            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
+            rig.ok(hipEventRecord(rig.ev_cmp[b], rig.s_cmp), "hipEventRecord");
+            rig.ok(hipStreamWaitEvent(rig.s_out, rig.ev_cmp[b], 0), "hipStreamWaitEvent");
+            if (k == 0) rig.ok(hipEventRecord(rig.t[4], rig.s_out), "hipEventRecord");
+            rig.ok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, rig.s_out), "hipMemcpyAsync D2H");
+            stats[1] += (double)out_bytes;
+            rig.ok(hipEventRecord(rig.ev_out[b], rig.s_out), "hipEventRecord");
         }
-        hipok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
-        hipok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
-        hipok(hipEventRecord(t1, s_out), "hipEventRecord");
-        hipok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
-        if (rc == PBH_OK && ms_total) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, t0, t1);
-            *ms_total = ms;
-        }
+        rig.ok(hipEventRecord(rig.t[3], rig.s_in), "hipEventRecord");
+        rig.ok(hipEventRecord(rig.t[5], rig.s_out), "hipEventRecord");
+        rig.finish(stats, ms_total);
+        stats[6] = (double)nchunk;
     }
-    if (reg_in) hipHostUnregister(const_cast<void*>(host_in));
-    if (reg_out) hipHostUnregister(host_out);
     for (int b = 0; b < 2; ++b) {
-        if (din[b]) hipFree(din[b]);
-        if (dout[b]) hipFree(dout[b]);
-        if (ev_in[b]) hipEventDestroy(ev_in[b]);
-        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
-        if (ev_out[b]) hipEventDestroy(ev_out[b]);
+        if (dwin[b]) (void)hipFree(dwin[b]);
+        if (dout[b]) (void)hipFree(dout[b]);
     }
-    if (t0) hipEventDestroy(t0);
-    if (t1) hipEventDestroy(t1);
-    if (s_in) hipStreamDestroy(s_in);
-    if (s_cmp) hipStreamDestroy(s_cmp);
-    if (s_out) hipStreamDestroy(s_out);
     if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
     return rc;
 }
 
-// The same overlap-save stream fed with RAW payload bytes (reader-side decode in front): per chunk only the bytes
-// of the blocks that hold its samples cross PCIe (2 bytes per 8-bit complex sample instead of 8), k_decode
-// writes them series-major on the device, and the chunk runs the pipeline without its de-interleave pass.
+// The same overlap-save stream fed with RAW payload bytes (reader-side decode in front): the bytes of the blocks that hold
+// the stream's samples cross PCIe once (2 bytes per 8-bit complex sample instead of 8) into the same two-window scheme, now
+// over FILE BYTES: an epoch's window holds the bytes from the (16-byte aligned) start of its first chunk's span to the end of
+// its last chunk's span, a chunk uploads only the bytes beyond its predecessor's span and a new epoch takes the bytes it
+// shares with the previous chunk from the other window.  k_decode writes each chunk series-major on the device, and the
+// chunk runs the pipeline without its de-interleave pass.
 int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_bytes, const pbh_raw_layout_t* L,
                               int64_t first, int64_t total_nsample, const unsigned char* conj_mask, float scale, void* host_out,
                               int64_t* nchunk_out, float* ms_total) {
@@ -3299,33 +3405,47 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
     if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
     if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
     const int64_t nchunk = (total_nsample - p->N) / hop + 1;
-    // spans of all chunks up front: bounds checks, and the size of the device raw buffers
+    // spans of all chunks up front: bounds checks, the epochs and the size of the device windows
     std::vector<DecodeSpan> spans((size_t)nchunk);
-    size_t cap = 0;
-    for (int64_t k = 0; k < nchunk; ++k) {
+    for (int64_t k = 0; k < nchunk; ++k)
         PBHCHECK(decode_span(L, first + k * hop, p->N, p->nchan, p->npol, raw_bytes, &spans[(size_t)k]));
-        cap = spans[(size_t)k].len > cap ? spans[(size_t)k].len : cap;
+    auto end_of = [&](int64_t k) { return spans[(size_t)k].off + spans[(size_t)k].len; };
+    // chunk k extends what chunk k-1 left on the device when its span starts inside (or right behind) that span and ends no earlier
+    auto extends = [&](int64_t k) {
+        return k > 0 && spans[(size_t)k].off >= spans[(size_t)k - 1].off && spans[(size_t)k].off <= end_of(k - 1) && end_of(k) >= end_of(k - 1);
+    };
+    struct Epoch { int64_t k0; size_t base; };
+    std::vector<Epoch> epochs;
+    std::vector<int> epoch_of((size_t)nchunk);
+    size_t win_bytes = 0;
+    {
+        const int64_t cap_chunks = stream_epoch_max() ? stream_epoch_max() : 64;
+        const size_t cap = stream_epoch_max() ? SIZE_MAX : stream_window_cap();
+        for (int64_t k = 0; k < nchunk; ++k) {
+            const bool fresh = epochs.empty() || !extends(k) || k - epochs.back().k0 >= cap_chunks ||
+                               end_of(k) - epochs.back().base > cap;
+            if (fresh) epochs.push_back({k, spans[(size_t)k].off - spans[(size_t)k].off % 16});
+            epoch_of[(size_t)k] = (int)epochs.size() - 1;
+            const size_t need = end_of(k) - epochs.back().base;
+            win_bytes = need > win_bytes ? need : win_bytes;
+        }
     }
     HIPCHECK(hipSetDevice(p->device));
     const bool sm = !(p->bsL || p->mixed || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                       p->N >= (1LL << 31)) && p->S > 1;
     const size_t row = sizeof(cf) * (size_t)p->S;
     const size_t out_bytes = row * (size_t)hop, host_out_bytes = out_bytes * (size_t)nchunk;
+    const int nwin = epochs.size() > 1 ? 2 : 1;
 
-    void* draw[2] = {nullptr, nullptr};
+    void* dwin[2] = {nullptr, nullptr};
     void* dout[2] = {nullptr, nullptr};
     void *dec = nullptr, *dconj = nullptr;
-    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    bool reg_in = false, reg_out = false;
-    int rc = PBH_OK;
-    auto hipok = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-        return e == hipSuccess;
-    };
+    StreamRig rig("pbh_dedisperse_stream_raw");
+    int& rc = rig.rc;
+    double* stats = p->stream_stats;
+    for (int i = 0; i < PBH_STREAM_NSTATS; ++i) stats[i] = 0.0;
     for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
-        if ((rc = dev_alloc(nullptr, &draw[b], cap + 16)) != PBH_OK) break;
+        if (b < nwin && (rc = dev_alloc(nullptr, &dwin[b], win_bytes + 16)) != PBH_OK) break;
         rc = dev_alloc(nullptr, &dout[b], out_bytes);
     }
     if (rc == PBH_OK) rc = dev_alloc(nullptr, &dec, row * (size_t)p->N);
@@ -3334,85 +3454,76 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
         for (int i = 0; i < p->S; ++i) any_conj |= conj_mask[i] != 0;
     if (rc == PBH_OK && any_conj) {
         rc = dev_alloc(nullptr, &dconj, (size_t)p->S);
-        if (rc == PBH_OK) hipok(xfer_h2d(dconj, conj_mask, (size_t)p->S, p->stream), "mask copy");
+        if (rc == PBH_OK) rig.ok(xfer_h2d(dconj, conj_mask, (size_t)p->S, p->stream), "mask copy");
     }
+    rig.pin(0, const_cast<void*>(host_raw), raw_bytes);
+    rig.pin(1, host_out, host_out_bytes);
+    rig.create(nchunk);
     if (rc == PBH_OK) {
-        const int pi = pin_host_range(const_cast<void*>(host_raw), raw_bytes);   // see pbh_dedisperse_stream
-        const int po = pin_host_range(host_out, host_out_bytes);
-        reg_in = pi == 0;
-        reg_out = po == 0;
-        if (pi < 0 || po < 0)
-            rc = fail(PBH_ERR_HIP, "pbh_dedisperse_stream_raw: the host buffers cannot be page-locked (hipHostRegister failed); "
-                                   "pageable memory is never handed to asynchronous copies");
-        hipok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
-        hipok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
-        hipok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
-        for (int b = 0; b < 2; ++b) {
-            hipok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
-            hipok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
-            hipok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
-        }
-        hipok(hipEventCreate(&t0), "hipEventCreate");
-        hipok(hipEventCreate(&t1), "hipEventCreate");
-    }
-    if (rc == PBH_OK) {
-        hipok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
-        hipok(hipEventRecord(t0, s_in), "hipEventRecord");
-        hipok(hipStreamWaitEvent(s_cmp, t0, 0), "hipStreamWaitEvent");
+        rig.ok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
+        rig.ok(hipEventRecord(rig.t[0], rig.s_in), "hipEventRecord");
+        rig.ok(hipEventRecord(rig.t[2], rig.s_in), "hipEventRecord");
+        rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.t[0], 0), "hipStreamWaitEvent");
         IoLayout io;
         if (sm) {
             io.in_layout = PBH_LAYOUT_SERIES_MAJOR;
             io.in_pitch = p->N;
         }
         for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const int b = (int)(k & 1);
-            const DecodeSpan& sp = spans[(size_t)k];
+            const int e = epoch_of[(size_t)k];
+            const Epoch& ep = epochs[(size_t)e];
+            const bool head = k == ep.k0;                       // first chunk of its epoch
+            const int w = (e & 1) % nwin, b = (int)(k & 1);
+            unsigned char* win = (unsigned char*)dwin[w];
             char* dst = (char*)host_out + (size_t)k * out_bytes;
-            if (k >= 2) hipok(hipStreamWaitEvent(s_in, ev_cmp[b], 0), "hipStreamWaitEvent");  // raw[b] consumed
-            // (+ off % 16 keeps the parity / alignment of the file offsets on the device)
-            unsigned char* dbase = (unsigned char*)draw[b] + sp.off % 16;
-            hipok(hipMemcpyAsync(dbase, (const char*)host_raw + sp.off, sp.len, hipMemcpyHostToDevice, s_in), "hipMemcpyAsync H2D");
-            hipok(hipEventRecord(ev_in[b], s_in), "hipEventRecord");
-            hipok(hipStreamWaitEvent(s_cmp, ev_in[b], 0), "hipStreamWaitEvent");
-            if (k >= 2) hipok(hipStreamWaitEvent(s_cmp, ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
+            // file bytes [lo, end_of(k)) are new to the device; [ep.base, lo) of a new epoch come out of the other window
+            const bool reuse = extends(k);
+            const size_t lo = reuse ? end_of(k - 1) : spans[(size_t)k].off;
+            if (head && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
+            if (end_of(k) > lo) {
+                rig.ok(hipMemcpyAsync(win + (lo - ep.base), (const char*)host_raw + lo, end_of(k) - lo, hipMemcpyHostToDevice, rig.s_in),
+                       "hipMemcpyAsync H2D");
+                stats[0] += (double)(end_of(k) - lo);
+            }
+            rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
+            rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
+            if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
+            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
+            if (head && k > 0) {
+                if (reuse && lo > ep.base) {
+                    const Epoch& prev = epochs[(size_t)e - 1];
+                    rig.ok(hipMemcpyAsync(win, (const unsigned char*)dwin[w ^ 1] + (ep.base - prev.base), lo - ep.base,
+                                          hipMemcpyDeviceToDevice, rig.s_cmp), "hipMemcpyAsync D2D");
+                    stats[7] += (double)(lo - ep.base);
+                }
+                rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
+            }
             if (rc == PBH_OK)
-                rc = decode_launch(dbase, (int64_t)sp.off, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
-                                   sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, s_cmp);
+                rc = decode_launch(win, (int64_t)ep.base, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
+                                   sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, rig.s_cmp);
             if (rc == PBH_OK) {
                 auto steps = build_steps(p, (const cf*)dec, (cf*)dout[b], DetectTail(), io);
-                rc = run_steps(steps, s_cmp);
+                rc = run_steps(steps, rig.s_cmp);
             }
-            hipok(hipEventRecord(ev_cmp[b], s_cmp), "hipEventRecord");
-            hipok(hipStreamWaitEvent(s_out, ev_cmp[b], 0), "hipStreamWaitEvent");
-            hipok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, s_out), "hipMemcpyAsync D2H");
-            hipok(hipEventRecord(ev_out[b], s_out), "hipEventRecord");
+            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
+            rig.ok(hipEventRecord(rig.ev_cmp[b], rig.s_cmp), "hipEventRecord");
+            rig.ok(hipStreamWaitEvent(rig.s_out, rig.ev_cmp[b], 0), "hipStreamWaitEvent");
+            if (k == 0) rig.ok(hipEventRecord(rig.t[4], rig.s_out), "hipEventRecord");
+            rig.ok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, rig.s_out), "hipMemcpyAsync D2H");
+            stats[1] += (double)out_bytes;
+            rig.ok(hipEventRecord(rig.ev_out[b], rig.s_out), "hipEventRecord");
         }
-        hipok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
-        hipok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
-        hipok(hipEventRecord(t1, s_out), "hipEventRecord");
-        hipok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
-        if (rc == PBH_OK && ms_total) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, t0, t1);
-            *ms_total = ms;
-        }
+        rig.ok(hipEventRecord(rig.t[3], rig.s_in), "hipEventRecord");
+        rig.ok(hipEventRecord(rig.t[5], rig.s_out), "hipEventRecord");
+        rig.finish(stats, ms_total);
+        stats[6] = (double)nchunk;
     }
-    if (reg_in) hipHostUnregister(const_cast<void*>(host_raw));
-    if (reg_out) hipHostUnregister(host_out);
     for (int b = 0; b < 2; ++b) {
-        if (draw[b]) hipFree(draw[b]);
-        if (dout[b]) hipFree(dout[b]);
-        if (ev_in[b]) hipEventDestroy(ev_in[b]);
-        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
-        if (ev_out[b]) hipEventDestroy(ev_out[b]);
+        if (dwin[b]) (void)hipFree(dwin[b]);
+        if (dout[b]) (void)hipFree(dout[b]);
     }
-    if (dec) hipFree(dec);
-    if (dconj) hipFree(dconj);
-    if (t0) hipEventDestroy(t0);
-    if (t1) hipEventDestroy(t1);
-    if (s_in) hipStreamDestroy(s_in);
-    if (s_cmp) hipStreamDestroy(s_cmp);
-    if (s_out) hipStreamDestroy(s_out);
+    if (dec) (void)hipFree(dec);
+    if (dconj) (void)hipFree(dconj);
     if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
     return rc;
 #endif

@@ -40,6 +40,7 @@
     int P##dedisperse_detect_layout(P##plan*, const void*, int, int64_t, void*, int, int);                      \
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
+    int P##stream_stats(const P##plan*, double*, int);                                                          \
     int P##dedisperse_stream_raw(P##plan*, const void*, size_t, const pbh_raw_layout_t*, int64_t, int64_t,      \
                                  const unsigned char*, float, void*, int64_t*, float*);                         \
     int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
@@ -208,6 +209,9 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in, void* out, int ns, int mo
 }
 int pbh_dedisperse_stream(pbh_plan* p, const void* in, int64_t total, void* out, int64_t* nchunk, float* ms) {
     FORWARD(p, pbh32_dedisperse_stream(P32(p), in, total, out, nchunk, ms), pbh64_dedisperse_stream(P64(p), in, total, out, nchunk, ms));
+}
+int pbh_stream_stats(const pbh_plan* p, double* out, int n) {
+    FORWARD(p, pbh32_stream_stats(P32(p), out, n), pbh64_stream_stats(P64(p), out, n));
 }
 int pbh_dedisperse_stream_raw(pbh_plan* p, const void* raw, size_t raw_bytes, const pbh_raw_layout_t* layout, int64_t first,
                               int64_t total, const unsigned char* conj_mask, float scale, void* out, int64_t* nchunk, float* ms) {

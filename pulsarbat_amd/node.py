@@ -15,7 +15,11 @@ import numpy as np
 from . import _hip
 from .device import DeviceArray
 
-__all__ = ["NodeBuffer", "PeerBuffer", "ChannelGather"]
+__all__ = ["NodeBuffer", "PeerBuffer", "ChannelGather", "GatherError", "MAX_NODE_BYTES"]
+
+# The largest buffer a peer has been SEEN to map (tools/ipc_probe.py: 2040 MiB maps in 0.1 ms, 2056 MiB never returns from
+# hipIpcOpenMemHandle).  pbh_node_alloc refuses anything larger; ChannelGather uses 1-GiB row-chunks.
+MAX_NODE_BYTES = 2040 << 20
 
 
 class _Cai:
@@ -92,22 +96,37 @@ class PeerBuffer:
     __del__ = close
 
 
+class GatherError(_hip.HipError):
+    """A step of the collective gather failed on some rank; raised on EVERY rank of the group."""
+
+
 class ChannelGather:
     """Gather of channel-sharded results by direct writes into the destination ranks' full-band blocks.
 
     ``mode="all"``: every rank ends up with the full ``(nout, nchan_total, npol)`` block (what ``gather=True`` returns
     on every rank); ``mode="root"``: only ``root`` does.  A destination's block is a run of ROW-CHUNKS, each its own
     allocation of at most ``chunk_bytes`` (1 GiB): mapping an allocation larger than 2 GiB into a peer process hangs in
-    this ROCm stack's IPC (measured: 2040 MiB maps in 0.1 ms, 2056 MiB never returns), and the blocks in question are
-    2 - 17 GB.  Every rank runs its plan once: the pipeline's last kernel writes the rank's channel slice into the chunks
-    of the first destination (``pbh_dedisperse_slices``; its own chunks when it is a destination), and ``pbh_place``
-    pushes the slice from there to the other destinations' chunks.  After the closing barrier a destination joins its
-    chunks into one contiguous array (a local pass at HBM speed, small beside the xGMI transfer it follows).
-    Reusable for repeated calls of one geometry (a stream of blocks): chunks and mappings are set up once.
+    this ROCm stack's IPC (measured between two processes on ONE device: 2040 MiB maps in 0.1 ms, 2056 MiB never returns;
+    the cross-device case is unobserved), and the blocks in question are 2 - 17 GB.  Every rank runs its plan once: the
+    pipeline's last kernel writes the rank's channel slice into the chunks of the first destination
+    (``pbh_dedisperse_slices``; its own chunks when it is a destination), and ``pbh_place`` pushes the slice from there to
+    the other destinations' chunks -- ONE STREAM PER DESTINATION, so that in ``mode="all"`` a rank drives its seven xGMI
+    links at once (the links are point to point: a single stream keeps one of them busy at a time).
+
+    Reusable for repeated calls of one geometry (a stream of blocks): chunks and mappings are set up once
+    (``shard.coherent_dedispersion_sharded`` keeps its gathers in a cache next to the plans).  The chunks are DOUBLE
+    BUFFERED: run ``n`` writes set ``n & 1``.  A peer can start the writes of run ``n + 1`` while a destination is still
+    reading run ``n``'s chunks, but it cannot start those of run ``n + 2`` before the destination has passed the closing
+    collective of run ``n + 1``, which it enters only after a device-wide synchronisation: no read-out is ever torn.
+
+    Failure handling: every collective step carries a status (``_agree``); a failure on one rank (allocation, mapping,
+    a plan that does not fit) raises :class:`GatherError` on ALL ranks after the same number of collectives, so nobody
+    is left waiting in a barrier.
     """
 
     def __init__(self, nout, nchan_local, npol, dtype, device, group=None, mode="all", root=0, chunk_bytes=None):
         import os
+        import torch
         import torch.distributed as dist
         if chunk_bytes is None:   # PBH_GATHER_CHUNK_BYTES: tests force many chunks at small sizes
             chunk_bytes = int(os.environ.get("PBH_GATHER_CHUNK_BYTES", 1 << 30))
@@ -116,6 +135,8 @@ class ChannelGather:
         self.group, self.mode, self.root = group, mode, int(root)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.nout, self.npol, self.dtype, self.device = int(nout), int(npol), np.dtype(dtype), int(device)
+        self._coll_device = torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.own, self.peers, self._streams, self._runs, self._broken = None, {}, {}, 0, False
         counts = [None] * self.world
         dist.all_gather_object(counts, int(nchan_local), group=group)
         self.counts = [int(c) for c in counts]
@@ -124,67 +145,130 @@ class ChannelGather:
         self.nchan_local = int(nchan_local)
         self.is_dest = mode == "all" or self.rank == self.root
         row_bytes = self.row_elems * self.dtype.itemsize
-        rows_per = max(1, min(int(chunk_bytes), (2 << 30) - 1) // max(row_bytes, 1))
-        self.part_rows = list(range(0, self.nout, rows_per)) + [self.nout] if self.nout > 0 else [0, 0]
+        rows_per = max(1, min(int(chunk_bytes), MAX_NODE_BYTES) // max(row_bytes, 1))
+        self.part_rows = list(range(0, self.nout, rows_per)) + [self.nout] if self.nout > 0 else [0]
         nparts = len(self.part_rows) - 1
-        self.own = None
-        if self.is_dest:
-            self.own = [NodeBuffer((self.part_rows[i + 1] - self.part_rows[i], self.nchan_total, self.npol), self.dtype,
-                                   self.device) for i in range(nparts)]
-        handles = [None] * self.world
-        dist.all_gather_object(handles, [b.handle() for b in self.own] if self.own is not None else None, group=group)
-        self.peers = {}
-        for r, hs in enumerate(handles):
-            if hs is not None and r != self.rank:
-                self.peers[r] = [PeerBuffer(h, self.device) for h in hs]
+        # 1. destinations allocate both chunk sets and export them; the handles travel WITH the status
+        err, mine = None, None
+        try:
+            if self.is_dest:
+                self.own = [[NodeBuffer((self.part_rows[i + 1] - self.part_rows[i], self.nchan_total, self.npol),
+                                        self.dtype, self.device) for i in range(nparts)] for _ in range(2)]
+                mine = [[b.handle() for b in bufs] for bufs in self.own]
+        except Exception as exc:
+            err = f"rank {self.rank}: {exc!r}"
+        got = [None] * self.world
+        dist.all_gather_object(got, (err, mine), group=group)
+        errs = [e for e, _ in got if e]
+        # 2. everybody maps the destinations' chunks
+        if not errs:
+            try:
+                for r, (_, hs) in enumerate(got):
+                    if hs is not None and r != self.rank:
+                        self.peers[r] = [[PeerBuffer(h, self.device) for h in hset] for hset in hs]
+            except Exception as exc:
+                err = f"rank {self.rank}: {exc!r}"
+        failed = self._agree(bool(errs) or err is not None)
+        if failed:   # agreed by all ranks: everybody unmaps, meets once more, then frees
+            self.close()
+            raise GatherError("gather set-up failed: " + "; ".join(errs + ([err] if err else []) or ["on another rank"]))
 
     @property
     def row_elems(self):
         return self.nchan_total * self.npol
 
-    def run(self, plan, x):
-        """Dedisperse this rank's shard ``x`` with ``plan`` and deliver the slice to every destination.
-        Returns the full-band DeviceArray on destination ranks, None elsewhere.  Collective: ends with a barrier."""
+    def _agree(self, failed):
+        """Collective: True on every rank if ``failed`` was true on any.  One small all-reduce -- this IS the step's
+        barrier, and it keeps the number of collectives per rank fixed on the error paths."""
         import torch
         import torch.distributed as dist
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=self._coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(flag.item())
+
+    def _stream_for(self, r):
+        import torch
+        if r not in self._streams:
+            self._streams[r] = torch.cuda.Stream(device=self.device)
+        return self._streams[r]
+
+    def run(self, plan, x, copy=True):
+        """Dedisperse this rank's shard ``x`` with ``plan`` and deliver the slice to every destination.
+        Returns the full-band DeviceArray on destination ranks, None elsewhere.  Collective.
+
+        ``copy=False`` returns the destination's row-chunks themselves (a list of DeviceArrays, rows ``part_rows[i] :
+        part_rows[i+1]``) instead of joining them into one array: no extra HBM pass, but the chunks are overwritten by the
+        next-but-one ``run`` of this gather."""
+        import torch
         lib = _hip.lib()
-        if plan.nchan != self.nchan_local or plan.npol != self.npol or plan.nout != self.nout:
-            raise ValueError("plan geometry does not match the gather")
-        off = self.chan_lo * self.npol
-        ncol = self.nchan_local * self.npol
-        dests = ([[b.ptr for b in self.own]] if self.own is not None else []) + \
-                [[p.ptr for p in ps] for _, ps in sorted(self.peers.items())]
-        if self.nout > 0 and ncol > 0:
-            plan.dedisperse_slices(x, dests[0], self.part_rows, self.row_elems, off)
-            esz = self.dtype.itemsize
-            stream = _hip._stream_ptr(self.device)
-            for d in dests[1:]:
-                for i, (src, dst) in enumerate(zip(dests[0], d)):
-                    rows = self.part_rows[i + 1] - self.part_rows[i]
-                    _hip._check(lib.pbh_place(self.device, stream, _hip._dtype_code(self.dtype),
-                                              C.c_void_p(src + off * esz), self.row_elems,
-                                              C.c_void_p(dst + off * esz), self.row_elems, rows, ncol))
-        torch.cuda.synchronize(self.device)   # this rank's writes (local and peer) have landed
-        dist.barrier(group=self.group)        # ... and so have everybody else's
+        gen = self._runs & 1
+        err = None
+        try:
+            if plan.nchan != self.nchan_local or plan.npol != self.npol or plan.nout != self.nout:
+                raise ValueError("plan geometry does not match the gather")
+            off = self.chan_lo * self.npol
+            ncol = self.nchan_local * self.npol
+            dests = ([(self.rank, [b.ptr for b in self.own[gen]])] if self.own is not None else []) + \
+                    [(r, [p.ptr for p in ps[gen]]) for r, ps in sorted(self.peers.items())]
+            if self.nout > 0 and ncol > 0 and dests:
+                first = dests[0][1]
+                plan.dedisperse_slices(x, first, self.part_rows, self.row_elems, off)
+                if len(dests) > 1:
+                    esz = self.dtype.itemsize
+                    main = torch.cuda.current_stream(self.device)
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    code = _hip._dtype_code(self.dtype)
+                    for r, d in dests[1:]:
+                        st = self._stream_for(r)
+                        st.wait_event(done)
+                        for i, (src, dst) in enumerate(zip(first, d)):
+                            rows = self.part_rows[i + 1] - self.part_rows[i]
+                            _hip._check(lib.pbh_place(self.device, C.c_void_p(st.cuda_stream), code,
+                                                      C.c_void_p(src + off * esz), self.row_elems,
+                                                      C.c_void_p(dst + off * esz), self.row_elems, rows, ncol))
+            torch.cuda.synchronize(self.device)   # this rank's writes (local and peer, all streams) have landed
+        except Exception as exc:
+            err = exc
+        self._runs += 1
+        if self._agree(err is not None):           # ... and so have everybody else's
+            raise GatherError(f"gather run failed on rank {self.rank}: {err!r}" if err is not None
+                              else "gather run failed on another rank") from err
         if self.own is None:
             return None
-        if len(self.own) == 1:
-            return DeviceArray(self.own[0].array.tensor.clone())   # (a copy: the chunks are re-used by the next run)
+        chunks = [b.array for b in self.own[gen]]
+        if not copy:
+            return chunks
         full = DeviceArray.empty((self.nout, self.nchan_total, self.npol), self.dtype, device=self.device)
-        for i, b in enumerate(self.own):
-            full.tensor[self.part_rows[i]:self.part_rows[i + 1]].copy_(b.array.tensor)
+        for i, c in enumerate(chunks):
+            full.tensor[self.part_rows[i]:self.part_rows[i + 1]].copy_(c.tensor)
         return full
 
-    def close(self):
-        import torch.distributed as dist
-        for ps in getattr(self, "peers", {}).values():
-            for p in ps:
-                p.close()
+    def _release(self, free):
+        for sets in getattr(self, "peers", {}).values():
+            for ps in sets:
+                for p in ps:
+                    p.close()
         self.peers = {}
-        try:
-            dist.barrier(group=self.group)   # nobody still has this rank's chunks mapped when they may be freed
-        except Exception:
-            pass
-        for b in (getattr(self, "own", None) or []):
-            b.close()
-        self.own = None
+        if free:
+            for bufs in (getattr(self, "own", None) or []):
+                for b in bufs:
+                    b.close()
+            self.own = None
+
+    def close(self):
+        """Collective: unmap the peers' chunks, agree that everybody has, free the own chunks.  After a failure that the
+        ranks did not agree on (``_broken``) the collective is skipped and the own chunks are left to process exit --
+        a leak, not a hang, and no peer is left with a dangling mapping."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        self._release(free=False)
+        ok = not self._broken
+        if ok:
+            try:
+                self._agree(False)   # nobody still has this rank's chunks mapped when they are freed
+            except Exception:
+                ok = False
+        if ok:
+            self._release(free=True)

@@ -18,13 +18,51 @@ chirps from scalars.  Two optional exchange steps exist:
 """
 
 import math
+import threading
 
 import numpy as np
 
 from . import units as u
 from .core import BasebandSignal
 
-__all__ = ["channel_slice", "shard_signal", "coherent_dedispersion_sharded", "dedisperse_detect_sharded"]
+__all__ = ["channel_slice", "shard_signal", "coherent_dedispersion_sharded", "dedisperse_detect_sharded", "release_gathers"]
+
+# ChannelGather objects by (thread, geometry, group, mode, root), next to the plan cache (transforms.dedispersion._PLANS):
+# a stream of blocks through coherent_dedispersion_sharded(gather=...) sets the destination chunks and their peer mappings
+# up ONCE.  Construction and release are collective, and every rank of a group makes the same sequence of calls, so the
+# ranks' caches stay in step.
+_GATHERS = {}
+_GATHERS_LOCK = threading.Lock()
+_GATHER_CACHE_SIZE = 4
+
+
+def _gather_for(plan, nchan, npol, dtype, dev, group, mode, root):
+    from .node import ChannelGather
+    key = (threading.get_ident(), plan.nout, int(nchan), int(npol), np.dtype(dtype).str, int(dev), id(group) if group is not None else None,
+           mode, int(root))
+    with _GATHERS_LOCK:
+        g = _GATHERS.get(key)
+    if g is None:
+        g = ChannelGather(plan.nout, nchan, npol, dtype, dev, group=group, mode=mode, root=root)
+        stale = []
+        with _GATHERS_LOCK:
+            _GATHERS[key] = g
+            mine = [k for k in _GATHERS if k[0] == key[0]]
+            while len(mine) > _GATHER_CACHE_SIZE:      # oldest first; the same choice on every rank
+                stale.append(_GATHERS.pop(mine.pop(0)))
+        for old in stale:
+            old.close()
+    return key, g
+
+
+def release_gathers():
+    """Collective: close the calling thread's cached gathers (destination chunks, peer mappings).  Call it on every rank of
+    the group, e.g. before ``destroy_process_group``; the memory is otherwise held for re-use by later calls."""
+    me = threading.get_ident()
+    with _GATHERS_LOCK:
+        stale = [_GATHERS.pop(k) for k in sorted((k for k in _GATHERS if k[0] == me), key=repr)]
+    for g in stale:
+        g.close()
 
 
 def channel_slice(nchan, world, rank):
@@ -119,7 +157,7 @@ def _global_rank(group, r):
 
 
 def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, chirp=None, chirp_src=None,
-                                  group=None, gather=False, root=0, device=None, variant="auto", _transform=None):
+                                  group=None, gather=False, root=0, device=None, variant="auto"):
     """Dedisperse this rank's channel shard consistently with the full-band call.
 
     z_local   this rank's BasebandSignal shard (``shard_signal``), host or device resident
@@ -132,24 +170,18 @@ def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_fre
               ``True`` / ``"all"``: every rank gets the full-band signal; ``"root"``: only rank ``root`` does
               (the others return ``None``: their slice was written into the root's block)
     device    GPU for host-resident shards (default: the process's current device)
-    _transform  test hook: ``f(x, start, stop, chan_freqs_hz, ref_hz) -> y`` replacing the HIP plan
-                (used by the CPU gloo tests with the oracle; never set by product code)
+
+    With ``gather`` the call is collective; for device data the gather's chunks and mappings are cached per geometry
+    (``release_gathers``).
     """
     if not isinstance(z_local, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
     if gather not in (False, True, "all", "root"):
         raise ValueError("gather must be False, True / 'all' or 'root'")
     start, stop = _full_band_crop(DM, len(z_local), z_local.sample_rate, band_min, band_max, ref_freq)
-    freqs = np.asarray(u.to_value(z_local.channel_freqs, u.Hz), dtype=np.float64)
-    ref_hz = u.to_value(ref_freq, u.Hz)
     kw = {}
     if z_local.start_time is not None:
         kw["start_time"] = z_local.start_time + start / z_local.sample_rate
-
-    if _transform is not None:
-        y = _transform(np.asarray(z_local.data), start, stop, freqs, ref_hz)
-        out = type(z_local).like(z_local, y, **kw)
-        return out if not gather else _all_gather_channels(out, band_min, band_max, group)
 
     from .device import DeviceArray
     from .transforms.dedispersion import _broadcast_chirp, _geometry, _plan_for
@@ -171,23 +203,26 @@ def coherent_dedispersion_sharded(z_local, DM, /, *, band_min, band_max, ref_fre
     plan, _ = _plan_for(z_local, DM, ref_freq, (start, stop), chirp=rows, variant=variant, per_pol=per_pol, dtype=dtype,
                         device=dev)
     if gather and on_device:
-        from .node import ChannelGather
         mode = "root" if gather == "root" else "all"
-        g = ChannelGather(plan.nout, pchan, ppol, dtype, dev, group=group, mode=mode, root=root)
+        key, g = _gather_for(plan, pchan, ppol, dtype, dev, group, mode, root)
         try:
             full = g.run(plan, x)
-        finally:
+        except Exception:
+            # a failed run raises on every rank (node.GatherError): all of them drop the gather, in step
+            with _GATHERS_LOCK:
+                _GATHERS.pop(key, None)
             g.close()
-        if full is None:   # a non-root rank of a root gather: its slice went to the root, nothing stays here
+            raise
+        if full is None:   # a non-root rank of a root gather: its slice was written into the root's block
             return None
         n_total = g.nchan_total // (npol if per_pol else 1)
         full = DeviceArray(full.tensor.reshape((plan.nout, n_total) + tuple(z_local.shape[2:])))
         return type(z_local).like(z_local, full, center_freq=center, freq_align="center", **kw)
     y = plan.dedisperse(x)   # device data: asynchronous on the current stream, like every other device transform
     out = type(z_local).like(z_local, y, **kw)
-    if not gather or on_device:
+    if not gather:
         return out
-    return _all_gather_channels(out, band_min, band_max, group)
+    return _gather_channels(out, band_min, band_max, group, root if gather == "root" else None)
 
 
 def dedisperse_detect_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, mode="I", nscrunch=1, group=None,
@@ -228,23 +263,26 @@ def dedisperse_detect_sharded(z_local, DM, /, *, band_min, band_max, ref_freq, m
     return full.numpy(), start
 
 
-def _all_gather_channels(shard, band_min, band_max, group):
-    """All-gather along axis 1.  Shards may be ragged in nchan, so sizes are exchanged first."""
+def _gather_channels(shard, band_min, band_max, group, root=None):
+    """Gather of host-resident shards along axis 1 over the group's own backend: to every rank (``root=None``) or to rank
+    ``root`` only (the others return None).  Shards may be ragged in nchan, so sizes are exchanged first."""
     import torch
     import torch.distributed as dist
-    from .device import DeviceArray
 
-    on_device = isinstance(shard.data, DeviceArray)
-    t = shard.data.tensor if on_device else torch.from_numpy(np.ascontiguousarray(shard.data))
-    world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([t.shape[1]], dtype=torch.int64, device=t.device), group=group)
+    t = torch.from_numpy(np.ascontiguousarray(shard.data))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, int(t.shape[1]), group=group)
     # channel-major contiguous pieces so every rank contributes one flat buffer
     mine = torch.view_as_real(t.transpose(0, 1).contiguous())
-    bufs = [torch.empty((int(s.item()),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
-            for s in sizes]
-    dist.all_gather(bufs, mine, group=group)
+    if root is None or rank == root:
+        bufs = [torch.empty((int(n),) + tuple(mine.shape[1:]), dtype=mine.dtype) for n in sizes]
+    if root is None:
+        dist.all_gather(bufs, mine, group=group)
+    else:
+        dist.gather(mine, bufs if rank == root else None, dst=_global_rank(group, root), group=group)
+        if rank != root:
+            return None
     full = torch.view_as_complex(torch.cat(bufs, dim=0)).transpose(0, 1).contiguous()
-    data = DeviceArray(full) if on_device else full.numpy()
     center = (band_min + band_max) / 2
-    return type(shard).like(shard, data, center_freq=center, freq_align="center")
+    return type(shard).like(shard, full.numpy(), center_freq=center, freq_align="center")

@@ -388,6 +388,37 @@ def test_stream_overlap_save(shape, chunk, dm):
     assert abs((y.start_time - z.start_time).to_value(u.s) - start / sr) < 1e-12
 
 
+@pytest.mark.parametrize("epoch", [1, 2, 3, 5])
+@pytest.mark.parametrize("shape,chunk,dm", [((1 << 18, 4, 2), 1 << 15, 20.0), ((1 << 16, 3), 1 << 13, 5.0),
+                                            ((200000, 1, 1), 1 << 14, 30.0)])
+def test_stream_uploads_every_row_once(shape, chunk, dm, epoch, monkeypatch):
+    """The overlap of consecutive chunks stays in HBM (two device windows, `epoch` chunks each): the host-to-device volume
+    is the input once (transforms.py:101-110: a stream's samples exist once), whatever the epoch length -- short epochs
+    exercise the window hand-over, odd row sizes the one-chunk-per-epoch fall-back -- and the result does not change."""
+    from pulsarbat_amd.transforms.dedispersion import _crop_bounds, _plan_for
+    monkeypatch.setenv("PBH_STREAM_EPOCH", str(epoch))
+    sr, fc = 1e6, 1e9
+    x = orc.synthetic_block(shape, 22)
+    z = make_signal(x, sr, fc)
+    head = z[:chunk]
+    bounds = _crop_bounds(head, pb.DM(dm), head.center_freq)
+    plan, _ = _plan_for(head, pb.DM(dm), head.center_freq, bounds)
+    y, ms = plan.dedisperse_stream(x)
+    hop = bounds[1] - bounds[0]
+    nchunk = (shape[0] - chunk) // hop + 1
+    assert nchunk >= 6 and len(y) == nchunk * hop
+    want = np.concatenate([orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, sr, fc)[0] for k in range(nchunk)], axis=0)
+    assert series_errors(y, want)[0] < RTOL_L2
+    st = plan.stream_stats()
+    row = 8 * int(np.prod(shape[1:]))
+    assert st["nchunk"] == nchunk and st["total_ms"] == pytest.approx(ms)
+    assert st["h2d_bytes"] == (chunk + (nchunk - 1) * hop) * row            # every row once
+    assert st["d2h_bytes"] == nchunk * hop * row
+    per_epoch = epoch if (hop * row) % 16 == 0 else 1
+    assert st["d2d_bytes"] == ((nchunk - 1) // per_epoch) * (chunk - hop) * row
+    assert 0 < st["overlap_efficiency"] <= 1.0 and st["kernel_ms"] > 0
+
+
 # ---- complex128 (float64 kernels): the reference accepts both dtypes (core.py:742) and keeps
 # dtype in = dtype out (tests/test_fft.py:53-54); its own tests feed complex128 ----------------------
 # With the HIP-generated chirp the bound is set by complex64 rounding of the chirp (the reference

@@ -1,4 +1,4 @@
-"""GPU tests of the channel-sharded path with the REAL plan (no _transform hook) and of BASELINE.json's
+"""GPU tests of the channel-sharded path with the REAL plan and of BASELINE.json's
 configs at full size against the oracle.
 
 * configs[1] (2^24 x 8 x 2, DM 56.77): ALL 16 series against the oracle.
@@ -203,8 +203,39 @@ def _world2_worker(rank, world, port, q, nchan):
         # user chirp held by rank 1 only, scattered by channel (the oracle's chirp: results must agree with `full`)
         chirp = orc.chirp_from_signal(dm, shape, sr, fc) if rank == 1 else None
         viac = shard.coherent_dedispersion_sharded(zl, pb.DM(dm), gather=True, chirp=chirp, chirp_src=1, **kw)
-        q.put((rank, np.asarray(full), full.channel_freqs.to_value(u.Hz),
-               None if root is None else np.asarray(root), np.asarray(viac)))
+        # a stream of blocks through the CACHED gather (set up once, double-buffered chunks), issued back to back with no
+        # synchronisation in between: every result must be its own block's, none torn by the next run's peer writes
+        ngather = len(shard._GATHERS)
+        outs = []
+        for k in range(5):
+            zk = type(zl).like(zl, pb.DeviceArray(zl.data.tensor * complex(k + 2, -k)))
+            outs.append(shard.coherent_dedispersion_sharded(zk, pb.DM(dm), gather=True, **kw))
+        assert len(shard._GATHERS) == ngather
+        ref = np.asarray(full)
+        stream_err = max(float(np.abs(np.asarray(o) - ref * complex(k + 2, -k)).max() / np.abs(ref).max())
+                         for k, o in enumerate(outs))
+        # one rank fails inside a run (its plan does not fit the gather): BOTH ranks get GatherError, nobody hangs,
+        # and close() still pairs up
+        from pulsarbat_amd import _hip
+        from pulsarbat_amd.node import ChannelGather, GatherError
+        from pulsarbat_amd.transforms.dedispersion import _plan_for
+        start, stop = shard._full_band_crop(pb.DM(dm), len(zl), zl.sample_rate, z.min_freq, z.max_freq, z.center_freq)
+        plan, _ = _plan_for(zl, pb.DM(dm), z.center_freq, (start, stop), device=0)
+        g = ChannelGather(plan.nout, zl.nchan, 2, np.complex64, 0, mode="all")
+        failed = ""
+        try:
+            if rank == 0:
+                with _hip.Plan(len(zl), zl.nchan, 2, start, stop - 32, device=0) as bad:
+                    g.run(bad, zl.data.contiguous())
+            else:
+                g.run(plan, zl.data.contiguous())
+        except GatherError as exc:
+            failed = str(exc)
+        again = g.run(plan, zl.data.contiguous())        # the gather is still usable afterwards
+        g.close()
+        shard.release_gathers()
+        q.put((rank, ref, full.channel_freqs.to_value(u.Hz),
+               None if root is None else np.asarray(root), np.asarray(viac), stream_err, failed, np.asarray(again)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -230,7 +261,7 @@ def test_sharded_hip_world2_on_one_gpu(nchan):
     shape = (shape[0], nchan, 2)
     x = orc.synthetic_block(shape, 41)
     want, start, stop = orc.coherent_dedispersion(x, dm, sr, fc)
-    for rank, full, freqs, root, viac in results:
+    for rank, full, freqs, root, viac, stream_err, failed, again in results:
         assert full.shape == want.shape
         assert per_series_l2(full, want).max() < RTOL_L2
         assert np.allclose(freqs, orc.channel_freqs(fc, sr, nchan))
@@ -238,6 +269,75 @@ def test_sharded_hip_world2_on_one_gpu(nchan):
         if root is not None:
             assert per_series_l2(root, want).max() < RTOL_L2
         assert per_series_l2(viac, want).max() < RTOL_L2
+        assert stream_err < 1e-5, f"rank {rank}: a result of the back-to-back stream differs ({stream_err:.2e})"
+        assert "gather run failed" in failed and (("rank 0" in failed) == (rank == 0))
+        assert np.array_equal(again, full)
+
+
+def _rccl_world1_worker(port, q):
+    """Every RCCL line of the sharded path, once, on a one-rank "nccl" group (the first GPU call of this process is the
+    process group's own)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.cuda.set_device(0)
+        shape, dm, sr, fc = _small_case()
+        x = orc.synthetic_block(shape, 43)
+        z = pb.DualPolarizationSignal(x, sample_rate=sr * u.Hz, center_freq=fc * u.Hz, pol_type="linear",
+                                      start_time=pb.Time(56000.0, format="mjd"))
+        zl = shard.shard_signal(z, 1, 0).to_device()
+        kw = dict(band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq)
+        out = {"backend": dist.get_backend()}
+        # X1 over RCCL: a DEVICE full-band chirp on rank 0, scattered by channel (dist.scatter of device tensors), then the
+        # gather by peer writes with its status all-reduces and object collectives over nccl
+        chirp = pb.DeviceArray.from_host(orc.chirp_from_signal(dm, shape, sr, fc))
+        y = shard.coherent_dedispersion_sharded(zl, pb.DM(dm), chirp=chirp, chirp_src=0, gather="all", **kw)
+        out["scatter_all"] = np.asarray(y)
+        y = shard.coherent_dedispersion_sharded(zl, pb.DM(dm), gather="root", **kw)
+        out["root"] = np.asarray(y)
+        # a chirp with ONE channel row: the broadcast branch (one-channel band so that the row is the right chirp)
+        x1 = np.ascontiguousarray(x[:, :1])
+        z1 = pb.DualPolarizationSignal(x1, sample_rate=sr * u.Hz, center_freq=fc * u.Hz, pol_type="linear").to_device()
+        kw1 = dict(band_min=z1.min_freq, band_max=z1.max_freq, ref_freq=z1.center_freq)
+        row = pb.DeviceArray.from_host(orc.chirp_from_signal(dm, x1.shape, sr, fc).reshape(shape[0], 1))
+        y = shard.coherent_dedispersion_sharded(z1, pb.DM(dm), chirp=row, chirp_src=0, gather=True, **kw1)
+        out["bcast"] = np.asarray(y)
+        # configs[4]'s exchange: the detected output gathered with a device all_gather
+        d, start = shard.dedisperse_detect_sharded(zl, pb.DM(dm), mode="I", nscrunch=64, gather=True, **kw)
+        out["detect"], out["start"] = np.asarray(d), start
+        shard.release_gathers()
+        dist.barrier()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_lines_at_world1():
+    """`shard._scatter_chirp`'s device branch (RCCL scatter, and the single-row broadcast), `ChannelGather`'s collectives
+    and `dedisperse_detect_sharded`'s device all-gather on an "nccl" process group of one rank, all against the oracle:
+    the first multi-GPU run must not be the first time these lines execute (core.py:298-309, 332-345 are the reference's
+    compute()/chunking they replace)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and out["backend"] == "nccl"
+    shape, dm, sr, fc = _small_case()
+    x = orc.synthetic_block(shape, 43)
+    want, start, stop = orc.coherent_dedispersion(x, dm, sr, fc)
+    assert per_series_l2(out["scatter_all"], want).max() < RTOL_L2
+    assert per_series_l2(out["root"], want).max() < RTOL_L2
+    want1 = orc.coherent_dedispersion(np.ascontiguousarray(x[:, :1]), dm, sr, fc)[0]
+    assert per_series_l2(out["bcast"], want1).max() < RTOL_L2
+    wd = orc.scrunch(orc.to_stokes(want, "linear")[:, :, 0], 64)
+    assert out["start"] == start and out["detect"].shape == wd.shape
+    assert np.abs(out["detect"] - wd).max() < 3e-5 * np.abs(wd).max() * 2
 
 
 @pytest.mark.parametrize("shape,dtype,total,first", [

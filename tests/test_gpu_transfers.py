@@ -47,9 +47,11 @@ def test_recycled_heap_range_h2d_then_d2h():
 
 
 def test_stream_entry_points_never_take_pageable_memory():
-    """pbh_dedisperse_stream on (a) ordinary numpy memory -- pinned by the call for its duration -- and (b) input and
-    output carved from ONE allocation so that they share a page: the call either pins both or fails with a HIP error;
-    it never falls back to asynchronous copies from pageable memory."""
+    """pbh_dedisperse_stream / _raw on (a) ordinary numpy memory -- pinned by the call for its duration -- and (b) a
+    buffer the call CANNOT pin: a page in its middle is unmapped, so hipHostRegister of the range fails (and its ends are
+    not pinned memory).  Both entry points must then return PBH_ERR_HIP ("page-locked"); there is no fall-back to
+    asynchronous copies from pageable memory -- one would die on the hole.  (hipHostRegister of a range that overlaps an
+    existing registration SUCCEEDS on this ROCm, so that cannot serve as the obstacle.)"""
     import pulsarbat_amd as pb
     from pulsarbat_amd import units as u
     from oracle import dedisp_oracle as orc
@@ -62,17 +64,51 @@ def test_stream_entry_points_never_take_pageable_memory():
     nchunk = (shape[0] - chunk) // hop + 1
     want = np.concatenate([orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, sr, fc)[0] for k in range(nchunk)])
     assert np.linalg.norm(np.asarray(y) - want) / np.linalg.norm(want) < 1e-5
-    # (b) adjacent input and output inside one buffer
+
+    import mmap
+    libc = C.CDLL(None, use_errno=True)
+    libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+
+    def holed(nbytes):
+        """Anonymous mapping of >= nbytes with ONE PAGE UNMAPPED in its middle: it cannot be page-locked (and a copy that
+        touched the hole would be a segmentation fault, not a wrong number -- the call has to fail before any copy)."""
+        size = (nbytes + 3 * mmap.PAGESIZE) & ~(mmap.PAGESIZE - 1)
+        mm = mmap.mmap(-1, size)
+        addr = C.addressof(C.c_char.from_buffer(mm))
+        hole = (addr + nbytes // 2) & ~(mmap.PAGESIZE - 1)
+        return mm, addr, hole
+
     with _hip.Plan(chunk, 2, 2, start, stop, device=0) as plan:
         plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, orc.channel_freqs(fc, sr, 2), fc)
-        nin, nout = x.size, nchunk * hop * 4
-        buf = np.empty(nin + nout, dtype=np.complex64)
-        xin = buf[:nin].reshape(shape)
-        xin[...] = x
-        out = buf[nin:].reshape(nchunk * hop, 2, 2)
-        try:
-            got, _ = plan.dedisperse_stream(xin, out=out)
-        except _hip.HipError as exc:
-            assert "page-locked" in str(exc)
-        else:
-            assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-5
+        good_in = x.copy()
+        good_out = np.empty((nchunk * hop, 2, 2), np.complex64)
+        keep = []
+        for victim in ("in", "out"):
+            nbytes = good_in.nbytes if victim == "in" else good_out.nbytes
+            mm, addr, hole = holed(nbytes)
+            arr = np.frombuffer(mm, dtype=np.complex64, count=nbytes // 8).reshape((-1, 2, 2))
+            if victim == "in":
+                arr[...] = good_in
+            assert libc.munmap(hole, mmap.PAGESIZE) == 0
+            keep.append((mm, arr))
+            with pytest.raises(_hip.HipError, match="page-locked"):
+                if victim == "in":
+                    plan.dedisperse_stream(arr, out=good_out)
+                else:
+                    plan.dedisperse_stream(good_in, out=arr)
+        # the raw entry point: same rule (8-bit complex payload, one block)
+        raw = np.random.default_rng(1).integers(0, 256, shape[0] * 4 * 2, dtype=np.uint8)
+        lay = dict(nbits=8, ncomp=2, code=0, blk_samples=shape[0], blk_stride=raw.size, hdr_bytes=0, elem0=0,
+                   stride_t=4, stride_c=2, stride_p=1)
+        mm, addr, hole = holed(raw.nbytes)
+        bad_raw = np.frombuffer(mm, dtype=np.uint8, count=raw.nbytes)
+        bad_raw[...] = raw
+        assert libc.munmap(hole, mmap.PAGESIZE) == 0
+        keep.append((mm, bad_raw))
+        with pytest.raises(_hip.HipError, match="page-locked"):
+            plan.dedisperse_stream_raw(bad_raw, lay, shape[0])
+        # nothing was left registered or broken: both entry points work on ordinary buffers afterwards
+        got, _ = plan.dedisperse_stream(good_in, out=good_out)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-5
+        plan.dedisperse_stream_raw(raw, lay, shape[0])
+        del arr, bad_raw

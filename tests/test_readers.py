@@ -323,7 +323,7 @@ class TestRawStream:
         assert y2.shape == y3.shape and y2.start_time.isclose(y3.start_time)
         assert np.linalg.norm(np.asarray(y2) - np.asarray(y3)) / np.linalg.norm(np.asarray(y3)) < 2e-6
 
-    def test_synthetic_blocks(self):
+    def test_synthetic_blocks(self, monkeypatch):
         """Headered blocks, offset-binary samples, a conjugation mask and a scale: equals the stream over
         the numpy-decoded array."""
         from pulsarbat_amd import _hip
@@ -347,6 +347,19 @@ class TestRawStream:
         yb, ms = plan.dedisperse_stream_raw(raw, lay, total, first=first, conj=conj, scale=1 / 64)
         assert yb.shape == ya.shape and ms > 0
         assert np.linalg.norm(yb - np.asarray(ya)) / np.linalg.norm(np.asarray(ya)) < 2e-6
+        # the payload bytes cross PCIe once: whole blocks from the first chunk's first block to the last chunk's last one
+        nchunk, hop = len(yb) // plan.nout, plan.nout
+        b0, b1 = first // blk_t, (first + (nchunk - 1) * hop + chunk - 1) // blk_t
+        st = plan.stream_stats()
+        assert st["nchunk"] == nchunk and st["h2d_bytes"] <= (b1 - b0 + 1) * stride and st["h2d_bytes"] >= (b1 - b0) * stride
+        # ... whatever the epoch length (window hand-over between epochs of 1, 2, 3 chunks): bit-identical results
+        assert nchunk == 3
+        for epoch in ("1", "2", "3"):
+            monkeypatch.setenv("PBH_STREAM_EPOCH", epoch)
+            yc, _ = plan.dedisperse_stream_raw(raw, lay, total, first=first, conj=conj, scale=1 / 64)
+            assert np.array_equal(yc, yb) and plan.stream_stats()["h2d_bytes"] == st["h2d_bytes"]
+            assert (plan.stream_stats()["d2d_bytes"] > 0) == (int(epoch) < nchunk)   # a hand-over per further epoch
+        monkeypatch.delenv("PBH_STREAM_EPOCH")
         with pytest.raises((ValueError, _hip.HipError)):
             plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk + 1)      # one sample beyond the buffer
         plan.dedisperse_stream_raw(raw, lay, chunk, first=nblk * blk_t - chunk)

@@ -1,7 +1,9 @@
-"""The N>1 path on CPU: world_size-2 gloo processes shard channels, run the per-shard transform
-(the oracle stands in for the HIP plan through the _transform test hook) and all-gather.  The
-result must equal the oracle on the full block, which pins the shard bookkeeping: channel
-partition, per-shard channel frequencies, full-band crop, start_time and the gather order."""
+"""The N>1 path on CPU: world_size-2 gloo processes shard channels, run the per-shard transform and gather.
+There is no GPU here, so the workers replace the plan factory (`transforms.dedispersion._plan_for`) by one whose
+plan runs the oracle -- the product entry point itself has no test hook.  The result must equal the oracle on the
+full block, which pins the shard bookkeeping: channel partition, per-shard channel frequencies, full-band crop,
+start_time, the gather order and the root-only gather.  The real plan runs the same entry point in
+tests/test_gpu_sharded.py."""
 
 import os
 import socket
@@ -25,15 +27,30 @@ def _free_port():
     return p
 
 
-def _oracle_transform(x, start, stop, freqs_hz, ref_hz):
-    chirp = np.stack([orc.transfer_function(DM, x.shape[0], 1 / SR, f, ref_hz) for f in freqs_hz], axis=1)
-    import scipy.fft
-    y = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * chirp[:, :, None], axis=0)
-    return np.ascontiguousarray(y[start:stop])
+class _OraclePlan:
+    """Stands in for _hip.Plan on the CPU box: same call, the oracle's arithmetic."""
+
+    def __init__(self, freqs_hz, ref_hz, start, stop):
+        self.freqs_hz, self.ref_hz, self.start, self.stop = freqs_hz, ref_hz, start, stop
+        self.nout = stop - start
+
+    def dedisperse(self, x):
+        import scipy.fft
+        chirp = np.stack([orc.transfer_function(DM, x.shape[0], 1 / SR, f, self.ref_hz) for f in self.freqs_hz], axis=1)
+        y = scipy.fft.ifft(scipy.fft.fft(x, axis=0) * chirp[:, :, None], axis=0)
+        return np.ascontiguousarray(y[self.start:self.stop])
+
+
+def _oracle_plan_for(z, dm, ref_freq, crop, chirp=None, variant="auto", per_pol=False, dtype=None, device=None):
+    assert chirp is None and not per_pol
+    freqs = np.asarray(u.to_value(z.channel_freqs, u.Hz), dtype=np.float64)
+    return _OraclePlan(freqs, u.to_value(ref_freq, u.Hz), crop[0], crop[1]), False
 
 
 def _worker(rank, world, port, q):
     import torch.distributed as dist
+    from pulsarbat_amd.transforms import dedispersion as dd
+    dd._plan_for = _oracle_plan_for          # this process only
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,12 +58,13 @@ def _worker(rank, world, port, q):
     z = pb.DualPolarizationSignal(x, sample_rate=SR * u.Hz, center_freq=FC * u.Hz, pol_type="linear",
                                   start_time=pb.Time(56000.0, format="mjd"))
     zl = shard.shard_signal(z, world, rank)
-    full = shard.coherent_dedispersion_sharded(
-        zl, pb.DM(DM), band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq,
-        gather=True, _transform=_oracle_transform)
-    local = shard.coherent_dedispersion_sharded(
-        zl, pb.DM(DM), band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq,
-        gather=False, _transform=_oracle_transform)
+    kw = dict(band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq, device=0)
+    full = shard.coherent_dedispersion_sharded(zl, pb.DM(DM), gather=True, **kw)
+    local = shard.coherent_dedispersion_sharded(zl, pb.DM(DM), gather=False, **kw)
+    at_root = shard.coherent_dedispersion_sharded(zl, pb.DM(DM), gather="root", root=1, **kw)
+    assert (at_root is None) == (rank != 1)
+    if at_root is not None:
+        assert np.array_equal(np.asarray(at_root), np.asarray(full)) and type(at_root) is type(full)
     q.put((rank, np.asarray(full), full.channel_freqs.to_value(u.Hz),
            (full.start_time - z.start_time).to_value(u.s), np.asarray(local).shape))
     dist.barrier()
