@@ -197,14 +197,17 @@ int pbh_dedisperse_slice(pbh_plan* plan, const void* in_dev, void* out_dev, int6
                          int64_t out_col_offset);
 /* The same with the destination's ROWS split over nparts buffers: part i receives output rows
  * [part_row[i], part_row[i+1]) (part_row[0] = 0, part_row[nparts] = stop - start) starting at part_dev[i].  A
- * destination block that peers map must be built from allocations of at most 2 GiB (larger ones hang in the
- * runtime's IPC mapping on this ROCm stack): the pipeline runs once and only its last pass runs once per part. */
+ * destination block that peers map must be built from allocations of at most PBH_NODE_MAX_BYTES (larger ones
+ * hang in the runtime's IPC mapping on this ROCm stack): the pipeline runs once and only its last pass runs
+ * once per part.                                                                                            */
 int pbh_dedisperse_slices(pbh_plan* plan, const void* in_dev, int nparts, void* const* part_dev,
                           const int64_t* part_row /* [nparts + 1] */, int64_t out_row_elems, int64_t out_col_offset);
 
 /* Sharing a device buffer between the ranks of one node (one process per GPU).  The destination rank
- * allocates with pbh_node_alloc (a whole device allocation, hence exportable; at most 2 GiB each -- a larger
- * block is several allocations, see pbh_dedisperse_slices), exports a 64-byte handle,
+ * allocates with pbh_node_alloc (a whole device allocation, hence exportable; at most PBH_NODE_MAX_BYTES each:
+ * 2040 MiB is the largest size seen to map into a peer process, 2056 MiB never returned from the peer's
+ * hipIpcOpenMemHandle -- observed between two processes on ONE device, the cross-device case is unobserved;
+ * a larger block is several allocations, see pbh_dedisperse_slices), exports a 64-byte handle,
  * ships it to its peers by any host channel (the Python host uses torch.distributed), and each peer maps
  * it with pbh_node_import (peer access over xGMI is enabled by the mapping) and writes into it with
  * pbh_dedisperse_slice.  The exporter must keep the buffer alive until every importer has called
@@ -220,6 +223,7 @@ int pbh_dedisperse_mix(pbh_plan* plan, const void* in_dev, void* out_dev, const 
 int pbh_place(int device, void* hip_stream, int dtype, const void* src_dev, int64_t src_row_elems, void* dst_dev,
               int64_t dst_row_elems, int64_t nrow, int64_t ncol);
 typedef struct { unsigned char bytes[64]; } pbh_ipc_handle_t;
+#define PBH_NODE_MAX_BYTES (2040ull << 20)
 int pbh_node_alloc(int device, size_t bytes, void** dev_ptr);
 int pbh_node_free(int device, void* dev_ptr);
 int pbh_node_export(int device, void* dev_ptr, pbh_ipc_handle_t* handle);

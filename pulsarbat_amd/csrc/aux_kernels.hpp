@@ -1234,8 +1234,8 @@ __global__ __launch_bounds__(256) void k_incoherent(const T* __restrict__ in, T*
 // series-major (time fastest) form of the same gather: out[s][t] = in[s][t + dly[s / per]], every series one contiguous run
 template <typename T>
 __global__ __launch_bounds__(256) void k_shift_rows(const T* __restrict__ in, int64_t ipitch, T* __restrict__ out, int64_t opitch,
-                                                    const int64_t* __restrict__ dly, int per, int64_t nout) {
-    const int s = blockIdx.y;
+                                                    const int64_t* __restrict__ dly, int per, int64_t nout, int s0) {
+    const int s = s0 + blockIdx.y;   // (the launch is cut into slabs of <= 65535 series: grid.y's limit)
     const T* src = in + (int64_t)s * ipitch + dly[s / per];
     T* dst = out + (int64_t)s * opitch;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nout; t += (int64_t)gridDim.x * blockDim.x) dst[t] = src[t];

@@ -2285,7 +2285,8 @@ int pbh_incoherent_series(int device, void* hip_stream, const void* in_dev, int6
                           int64_t out_pitch_words, int64_t nout, int nchan, int series_per_chan, int unit_words,
                           const int64_t* delay /*[nchan] host, >= 0*/) {
     if (!in_dev || !out_dev || !delay) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (nout < 0 || nchan <= 0 || series_per_chan <= 0 || (unit_words != 1 && unit_words != 2 && unit_words != 4))
+    if (nout < 0 || nchan <= 0 || series_per_chan <= 0 || (unit_words != 1 && unit_words != 2 && unit_words != 4) ||
+        (int64_t)nchan * series_per_chan > INT32_MAX)
         return fail(PBH_ERR_INVALID, "bad size");
     if (in_pitch_words % unit_words || out_pitch_words % unit_words) return fail(PBH_ERR_INVALID, "pitch is not a whole number of elements");
     if (nout == 0) return PBH_OK;
@@ -2298,13 +2299,16 @@ int pbh_incoherent_series(int device, void* hip_stream, const void* in_dev, int6
         const int64_t ip = in_pitch_words / unit_words, op = out_pitch_words / unit_words;
         int64_t bx = (nout + 255) / 256;
         if (bx > 4096) bx = 4096;
-        const dim3 grid((unsigned)bx, (unsigned)(nchan * series_per_chan));
-        if (unit_words == 4)
-            hipLaunchKernelGGL((k_shift_rows<uint4>), grid, dim3(256), 0, st, (const uint4*)in_dev, ip, (uint4*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
-        else if (unit_words == 2)
-            hipLaunchKernelGGL((k_shift_rows<uint2>), grid, dim3(256), 0, st, (const uint2*)in_dev, ip, (uint2*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
-        else
-            hipLaunchKernelGGL((k_shift_rows<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)in_dev, ip, (uint32_t*)out_dev, op, (const int64_t*)d, series_per_chan, nout);
+        const int64_t nser = (int64_t)nchan * series_per_chan;
+        for (int64_t s0 = 0; s0 < nser; s0 += 65535) {   // grid.y holds at most 65535 series
+            const dim3 grid((unsigned)bx, (unsigned)(nser - s0 < 65535 ? nser - s0 : 65535));
+            if (unit_words == 4)
+                hipLaunchKernelGGL((k_shift_rows<uint4>), grid, dim3(256), 0, st, (const uint4*)in_dev, ip, (uint4*)out_dev, op, (const int64_t*)d, series_per_chan, nout, (int)s0);
+            else if (unit_words == 2)
+                hipLaunchKernelGGL((k_shift_rows<uint2>), grid, dim3(256), 0, st, (const uint2*)in_dev, ip, (uint2*)out_dev, op, (const int64_t*)d, series_per_chan, nout, (int)s0);
+            else
+                hipLaunchKernelGGL((k_shift_rows<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)in_dev, ip, (uint32_t*)out_dev, op, (const int64_t*)d, series_per_chan, nout, (int)s0);
+        }
         e = hipGetLastError();
     }
     const hipError_t ef = hipFreeAsync(d, st);

@@ -260,11 +260,13 @@ static int hip_fail(const char* what, hipError_t e) {
 int pbh_node_alloc(int device, size_t bytes, void** dev_ptr) {
     if (!dev_ptr || bytes == 0) return fail_here(PBH_ERR_INVALID, "pbh_node_alloc: bad argument");
     *dev_ptr = nullptr;
-    // a peer's hipIpcOpenMemHandle on an allocation larger than 2 GiB never returns on this ROCm stack (measured:
-    // 2040 MiB maps in 0.1 ms, 2056 MiB hangs): refuse here, where it is an error, rather than there, where it is a hang
-    if (bytes > 0x7fffffffULL)
-        return fail_here(PBH_ERR_UNSUPPORTED, "pbh_node_alloc: a buffer that peers map must be at most 2 GiB - 1 bytes; "
-                                              "build larger blocks from row-chunks (pbh_dedisperse_slices)");
+    // a peer's hipIpcOpenMemHandle on a large allocation never returns on this ROCm stack (measured between two processes on
+    // one device: 2040 MiB maps in 0.1 ms, 2056 MiB hangs; the cross-device case is unobserved).  The limit is the largest
+    // size SEEN to map, not "just under 2 GiB": a request of 2^31 - 1 bytes rounds up to exactly 2^31 in the allocator.
+    // Refuse here, where it is an error, rather than there, where it is a hang.
+    if (bytes > PBH_NODE_MAX_BYTES)
+        return fail_here(PBH_ERR_UNSUPPORTED, "pbh_node_alloc: a buffer that peers map must be at most 2040 MiB (beyond 2 GiB the "
+                                              "peer's mapping call hangs); build larger blocks from row-chunks (pbh_dedisperse_slices)");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail("hipSetDevice", e);
     e = hipMalloc(dev_ptr, bytes);   // a whole allocation of its own: exportable, unlike a caching allocator's sub-block

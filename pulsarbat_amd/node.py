@@ -57,7 +57,7 @@ class NodeBuffer:
         if self._array is None:
             import torch
             t = torch.as_tensor(_Cai(self.ptr, self.shape, self.dtype, self), device=torch.device("cuda", self.device))
-            if t.data_ptr() != self.ptr:
+            if self.nbytes and t.data_ptr() != self.ptr:   # (an empty tensor has no storage to point anywhere)
                 raise _hip.HipError("torch copied the node buffer instead of viewing it")
             self._array = DeviceArray(t)
         return self._array

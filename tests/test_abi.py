@@ -104,13 +104,17 @@ def test_c_consumer_runs_the_hot_path(tmp_path):
 
 
 def test_node_alloc_refuses_buffers_that_would_hang_a_peer():
-    """pbh_node_alloc: allocations that another process may map are limited to 2 GiB - 1 (a larger one makes the peer's
-    hipIpcOpenMemHandle hang on this ROCm stack); the refusal needs no GPU."""
+    """pbh_node_alloc: allocations that another process may map are limited to 2040 MiB, the largest size that was SEEN
+    to map (2056 MiB made the peer's hipIpcOpenMemHandle hang on this ROCm stack; 2^31 - 1 bytes rounds up to 2^31 in
+    the allocator, so "just under 2 GiB" is not a safe limit); the refusal needs no GPU."""
     import ctypes as C
     from pulsarbat_amd import _hip
     lib = _hip.lib()
     ptr = C.c_void_p()
-    rc = lib.pbh_node_alloc(0, (1 << 31), C.byref(ptr))
-    assert rc == -2 and not ptr.value            # PBH_ERR_UNSUPPORTED
-    assert b"2 GiB" in lib.pbh_last_error()
+    from pulsarbat_amd.node import MAX_NODE_BYTES
+    assert MAX_NODE_BYTES == 2040 << 20
+    for nbytes in ((1 << 31), (1 << 31) - 1, MAX_NODE_BYTES + 1):
+        rc = lib.pbh_node_alloc(0, nbytes, C.byref(ptr))
+        assert rc == -2 and not ptr.value            # PBH_ERR_UNSUPPORTED
+        assert b"2040 MiB" in lib.pbh_last_error()
     assert lib.pbh_node_alloc(0, 0, C.byref(ptr)) == -1

@@ -89,6 +89,20 @@ def test_incoherent_series_major_arrays():
 
 
 @pytest.mark.gpu
+def test_incoherent_series_major_more_series_than_a_grid_dimension():
+    """70 000 series (what a 4096-point channelisation of a few streams, held series-major, looks like): the shifted-copy
+    kernel is launched in slabs of at most 65 535 series (grid.y's limit) -- bit exact, the last series included."""
+    nchan, n = 35000, 96
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((n, nchan, 2)) + 1j * rng.standard_normal((n, nchan, 2))).astype(np.complex64)
+    z = pb.DualPolarizationSignal(x, sample_rate=1 * u.kHz, center_freq=400 * u.MHz, pol_type="linear")
+    zs = type(z).like(z, z.to_device().data.to_series_major())
+    y = pb.incoherent_dedispersion(zs, pb.DM(5.0))
+    want, _ = orc.incoherent_dedispersion(x, 5.0, 1e3, 400e6, 1e3)
+    assert y.shape == want.shape and 0 < want.shape[0] < n and np.array_equal(np.asarray(y), want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,dtype", [((200003, 8, 2), np.complex64), ((150001, 8, 4), np.float32),
                                          ((100000, 4, 1), np.complex64), ((131072, 6, 2), np.complex64)])
 def test_incoherent_large_blocks_two_pass(shape, dtype):
