@@ -539,8 +539,15 @@ template <int S, bool MIX = false>
 __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
                                                          int64_t N, int64_t plane, int64_t nvalid,
                                                          const double* __restrict__ ft = nullptr) {
-    constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;  // 8 float4 per thread
-    __shared__ cf lds[S * LD];
+    // LDS image: series s at s * LD.  2 <= S <= 16: no padding, every series' row ROTATED by an even amount instead
+    // (slot = s TN + (n + c(s)) mod TN, c = (s >> 1)(32 / S)): the 16 lanes of a ds_write_b64 group -- 32 / S time samples of S / 2
+    // even series -- land on 16 different slots mod 16, and a lane's two samples of the planar side are one aligned 16-byte
+    // read.  With LD = TN + 1 that read was a ds_read2_b64 whose lanes are two slots apart: 2-way bank conflicts, 1.68e7
+    // SQ_LDS_BANK_CONFLICT cycles per launch at config 2 (profiles/r02z3_*).  Other S keep the padded image.
+    constexpr bool SWZ = S >= 2 && S <= 16;
+    constexpr int TN = kTrElems / S, LD = SWZ ? TN : TN + 1, NV = kTrElems / 2 / 256;  // 8 float4 per thread
+    __shared__ __attribute__((aligned(16))) cf lds[S * LD];
+    auto slot = [](int s, int n) { return SWZ ? s * TN + ((n + (s >> 1) * (32 / (SWZ ? S : 32))) & (TN - 1)) : s * LD + n; };
     const int64_t n0 = (int64_t)blockIdx.x * TN;
     const float4* src = reinterpret_cast<const float4*>(in + n0 * S);
     float4 v[NV];
@@ -570,8 +577,8 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
             lds[e] = make_cf(v[j].x, v[j].y);
             lds[e + 1] = make_cf(v[j].z, v[j].w);
         } else {
-            lds[s * LD + n] = make_cf(v[j].x, v[j].y);
-            lds[(s + 1) * LD + n] = make_cf(v[j].z, v[j].w);
+            lds[slot(s, n)] = make_cf(v[j].x, v[j].y);
+            lds[slot(s + 1, n)] = make_cf(v[j].z, v[j].w);
         }
     }
     __syncthreads();
@@ -579,7 +586,15 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
     for (int j = 0; j < NV; ++j) {
         const int pidx = threadIdx.x + 256 * j;
         const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
-        cf a = lds[s * LD + n], b = lds[s * LD + n + 1];
+        cf a, b;
+        if constexpr (SWZ) {
+            const float4 q = *reinterpret_cast<const float4*>(&lds[slot(s, n)]);
+            a = make_cf(q.x, q.y);
+            b = make_cf(q.z, q.w);
+        } else {
+            a = lds[s * LD + n];
+            b = lds[s * LD + n + 1];
+        }
         if constexpr (MIX) {
             const double f = ft[s];
             a = mix_sample(a, f, n0 + n);
@@ -594,8 +609,12 @@ template <int S, bool PITCHED = false, bool SHIFTED = false>
 __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
                                                          int64_t start, int64_t plane, int64_t opitch,
                                                          const int64_t* __restrict__ dly = nullptr) {
-    constexpr int TN = kTrElems / S, LD = TN + 1, NV = kTrElems / 2 / 256;
-    __shared__ cf lds[S * LD];
+    // LDS image as in k_deinterleave_p2; here the interleaved side READS 8 bytes per lane in groups of 32 lanes (64 / S time
+    // samples of S / 2 even series), so the rotation is c = (s >> 1)(64 / S), and the planar side writes 16 aligned bytes.
+    constexpr bool SWZ = S >= 2 && S <= 16;
+    constexpr int TN = kTrElems / S, LD = SWZ ? TN : TN + 1, NV = kTrElems / 2 / 256;
+    __shared__ __attribute__((aligned(16))) cf lds[S * LD];
+    auto slot = [](int s, int n) { return SWZ ? s * TN + ((n + (s >> 1) * (64 / (SWZ ? S : 64))) & (TN - 1)) : s * LD + n; };
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
     cf a[NV], b[NV];
 #pragma unroll
@@ -611,8 +630,12 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
     for (int j = 0; j < NV; ++j) {
         const int pidx = threadIdx.x + 256 * j;
         const int s = pidx / (TN / 2), n = 2 * (pidx % (TN / 2));
-        lds[s * LD + n] = a[j];
-        lds[s * LD + n + 1] = b[j];
+        if constexpr (SWZ) {
+            *reinterpret_cast<float4*>(&lds[slot(s, n)]) = make_float4(a[j].x, a[j].y, b[j].x, b[j].y);
+        } else {
+            lds[s * LD + n] = a[j];
+            lds[s * LD + n + 1] = b[j];
+        }
     }
     __syncthreads();
     float4* dst = reinterpret_cast<float4*>(out + (t0 - start) * S);
@@ -625,8 +648,8 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
             x = lds[e];
             y = lds[e + 1];
         } else {
-            x = lds[s * LD + n];
-            y = lds[(s + 1) * LD + n];
+            x = lds[slot(s, n)];
+            y = lds[slot(s + 1, n)];
         }
         if constexpr (PITCHED)   // rows are a slice of a wider array (S >= 2, opitch and the base even: 16-byte vectors)
             *reinterpret_cast<float4*>(out + (t0 - start + n) * opitch + s) = make_float4(x.x, x.y, y.x, y.y);

@@ -377,6 +377,13 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
         constexpr bool LAST = (NS * RAD == M);
         constexpr int SI = stage_index(M, NS, R, ORD);
         constexpr bool PAIRS = NB > 1 && ((PIN && NS == 1) || (POUT && LAST));   // bases NB tau + q in this stage
+        // the exchange in front of a pair-adjacent LAST stage is not padded: its writes are lane-consecutive slots as they
+        // stand (conflict-free), and without the pad slots a thread's two adjacent points are one ALIGNED 16-byte read
+        // (ds_read_b128, 16 lanes = 256 contiguous bytes).  Padded, that read became a ds_read2_b64 with its 16-lane groups two
+        // slots apart: 2-way bank conflicts on every access (1.68e7 SQ_LDS_BANK_CONFLICT cycles per launch of k_rowp16).
+        constexpr int NRAD_N = LAST ? 1 : stage_radix(M, NS * RAD, R, ORD);
+        constexpr bool NEXT_IS_PAIRS = !LAST && POUT && NS * RAD * NRAD_N == M && R / NRAD_N == 2 && sizeof(cf) == 8;
+        constexpr bool WPAD = PAD && !NEXT_IS_PAIRS;
         static_assert(!(PIN || POUT) || (!XS && !WSYNC), "pair-adjacent stages: plain exchange only");
         hk(ic<SI>{}, ic<-1>{});
 #pragma unroll
@@ -411,14 +418,14 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 const int base = (jb - k) * RAD + k;
                 // linear form is exact when the step is a multiple of 32 slots, or when it is the
                 // first stage of a row tile (base*PS+fofs is a multiple of RAD, u < RAD <= 32)
-                constexpr bool LIN = !PAD || ((NS * PS) % 32 == 0) || (NS == 1 && PS == 1 && 32 % RAD == 0);
+                constexpr bool LIN = !WPAD || ((NS * PS) % 32 == 0) || (NS == 1 && PS == 1 && 32 % RAD == 0);
                 if constexpr (LIN) {
-                    cf* wp = lds + lds_phys<PAD>(base * PS + fofs);
+                    cf* wp = lds + lds_phys<WPAD>(base * PS + fofs);
 #pragma unroll
-                    for (int u = 0; u < RAD; ++u) wp[lds_lin<PAD>(u * NS * PS)] = t[u];
+                    for (int u = 0; u < RAD; ++u) wp[lds_lin<WPAD>(u * NS * PS)] = t[u];
                 } else {
 #pragma unroll
-                    for (int u = 0; u < RAD; ++u) lds[lds_phys<PAD>((base + u * NS) * PS + fofs)] = t[u];
+                    for (int u = 0; u < RAD; ++u) lds[lds_phys<WPAD>((base + u * NS) * PS + fofs)] = t[u];
                 }
             }
         }
@@ -453,11 +460,22 @@ __device__ __forceinline__ void fft_tile(cf (&v)[R], cf* lds, int tau, int fofs,
                 // v[q + j NNB] = position (NNB tau + q) + j M/NRAD: NNB consecutive slots per read (M/NRAD is a multiple of 32
                 // slots for row tiles, so the padded map stays linear in j; the pair never straddles a pad slot)
                 static_assert(PS == 1 && (M / NRAD) % 32 == 0 && 32 % NNB == 0, "pair-adjacent last stage: row tiles");
-                const cf* rp = lds + lds_phys<PAD>(NNB * tau + fofs);
+                if constexpr (NEXT_IS_PAIRS) {
+                    static_assert(NS % 16 == 0 || NS == 1, "unpadded exchange: lane-consecutive writes");
+                    const float4* rp4 = reinterpret_cast<const float4*>(lds + NNB * tau + fofs);   // fofs even, lds 16-byte aligned
 #pragma unroll
-                for (int j = 0; j < NRAD; ++j)
+                    for (int j = 0; j < NRAD; ++j) {
+                        const float4 x = rp4[j * (M / NRAD) / 2];
+                        v[2 * j] = make_cf(x.x, x.y);
+                        v[2 * j + 1] = make_cf(x.z, x.w);
+                    }
+                } else {
+                    const cf* rp = lds + lds_phys<PAD>(NNB * tau + fofs);
 #pragma unroll
-                    for (int q = 0; q < NNB; ++q) v[q + j * NNB] = rp[lds_lin<PAD>(j * (M / NRAD)) + q];
+                    for (int j = 0; j < NRAD; ++j)
+#pragma unroll
+                        for (int q = 0; q < NNB; ++q) v[q + j * NNB] = rp[lds_lin<PAD>(j * (M / NRAD)) + q];
+                }
             } else {
             constexpr bool RLIN = !PAD || ((MR * PS) % 32 == 0);
             if constexpr (RLIN) {

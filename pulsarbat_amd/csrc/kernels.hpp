@@ -199,9 +199,10 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     const int f = tid % F, tau = tid / F;
     const uint32_t ngrp = (uint32_t)(p.N2 / F);
     const uint32_t ntile = ngrp * (uint32_t)p.S * (uint32_t)p.P;   // (series, row block, column group)
-    const int voff = (tau * p.N2 + f) * (int)sizeof(cf);
-    const int stepb = MR * p.N2 * (int)sizeof(cf);
-    const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * p.N2 + F) * (int64_t)sizeof(cf));
+    const int pitch = p.N2;   // elements between consecutive rows of the planar arrays (a padded pitch was measured: see oop_mode)
+    const int voff = (tau * pitch + f) * (int)sizeof(cf);
+    const int stepb = MR * pitch * (int)sizeof(cf);
+    const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * pitch + F) * (int64_t)sizeof(cf));
     const int shift = p.tw.shift;
     const int64_t lomask = (1LL << shift) - 1;
     const uint32_t c0 = (uint32_t)p.crop_start, c1 = (uint32_t)p.crop_stop;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     auto group_of = [&](uint32_t t) -> int { return (int)(t % ngrp); };
     auto block_of = [&](uint32_t t) -> int { return (int)((t / ngrp) % (uint32_t)p.P); };
     auto series_of = [&](uint32_t t) -> int { return (int)(t / (ngrp * (uint32_t)p.P)); };
-    const int64_t blk = (int64_t)M * p.N2;   // elements per row block
+    const int64_t blk = (int64_t)M * pitch;   // elements per row block
     const cf* ldb = p.ld ? p.ld : p.data;
     const int64_t ldp = p.ld ? p.ld_plane : p.plane;
     auto tile_rsrc = [&](uint32_t t) {   // where tile t is loaded from
@@ -608,6 +609,7 @@ struct RowpParams {
     unsigned* counter;   // pair hand-out (zeroed before the launch); null = static stride
     int cP = 1;          // phase rows stored in split order cP x (N1/cP), data rows in natural order (RowParams::cP)
     int phase16 = 0;     // the phase rows are stored in k_rowp16's order (ChirpParams::phase16): k_rowp16 runs the pass
+    cf* out = nullptr;   // k_rowp16: rows are stored here (same geometry) instead of in place -- the ping-pong schedule
 };
 
 template <int M, int R>
@@ -749,6 +751,13 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
         const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + k1;
         return make_rsrc(p.data + row * M, (uint32_t)(M * sizeof(cf)));
     };
+    cf* const obase = p.out ? p.out : p.data;
+    auto out_rsrc = [&](uint32_t u, int pol) {   // where the tile's rows are stored (the row itself unless p.out is set)
+        if (u >= npair) return make_rsrc(obase, 0);
+        const uint32_t chan = u / (uint32_t)p.N1, k1 = u - chan * (uint32_t)p.N1;
+        const int64_t row = ((int64_t)chan * p.npol + pol) * p.N1 + k1;
+        return make_rsrc(obase + row * M, (uint32_t)(M * sizeof(cf)));
+    };
     auto load_pair = [&](rsrc_t r, int j, cf& a, cf& b) {   // points (2 tau, 2 tau + 1) + 1024 j
         const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff16, j * STEP16, 0);
         a = make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
@@ -765,6 +774,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
     uint32_t unx = u + G;
     int pol = 0;
     rsrc_t rd = row_rsrc(u, 0);
+    rsrc_t ws = out_rsrc(u, 0);
     cf v[R];
 #pragma unroll
     for (int j = 0; j < R / 2; ++j) load_pair(rd, j, v[2 * j], v[2 * j + 1]);
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
         if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true, false, false, decltype(hk), 0, false, true>(v, lds, tau, 0, wi, hk);
         else __syncthreads();
 #pragma unroll
-        for (int j = 0; j < R / 2; ++j) store_pair(rd, j, v[2 * j], v[2 * j + 1]);
+        for (int j = 0; j < R / 2; ++j) store_pair(ws, j, v[2 * j], v[2 * j + 1]);
 #pragma unroll
         for (int k = 0; k < R / 2; ++k)
             if (cnt < R / 2) { load_pair(rdn, cnt, nx[2 * cnt], nx[2 * cnt + 1]); ++cnt; }
@@ -844,6 +854,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
         }
         pol = poln;
         rd = rdn;
+        ws = out_rsrc(un, poln);
     }
 }
 #endif  // !PBH_F64

@@ -228,6 +228,7 @@ struct pbh_plan {
     int perm_w = 0;  // chirp row order: 0 natural, 8 = wave-decoupled row kernel (k_row2)
 
     cf* work = nullptr;      // planar workspace, S * N
+    cf* work2 = nullptr;     // second planar workspace: the middle passes of the power-of-two planar pipeline ping-pong (oop_ok)
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
     float* chirp_phase = nullptr;  // same order, revolutions: what k_rowp reads (generated chirps only)
     bool has_phase = false;
@@ -733,6 +734,25 @@ struct DetectTail {
     int mode = 0, nscrunch = 1;
 };
 
+// Ping-pong schedule of the planar pipeline's middle passes (column, row, column): each pass reads one planar buffer and
+// writes the other instead of updating `work` in place.  OPT-IN (PBH_OOP=1), because it does not pay: a plain in-place
+// streaming update of the column pattern tops out at 5.26 TB/s and the same traffic out of place with a padded row pitch at
+// 5.58 (tools/micro/colcopy.hip, profiles/r03_colcopy.txt), but in the real passes the schedule changes nothing at the
+// product's pitch (column passes 0.846 -> 0.856 / 0.754 -> 0.759 ms, row pass 1.00 -> 0.99) and 1.3 % of the step with a
+// padded pitch on top (profiles/r03_colq_pitch_oop.txt) -- for a second workspace of S * N elements.
+static int oop_mode() {
+    static const int m = [] { const char* e = getenv("PBH_OOP"); return e ? atoi(e) : 0; }();
+    return m;
+}
+static cf* ensure_work2(pbh_plan* p) {
+    if (!p->work2 && p->work) {
+        void* q = nullptr;
+        if (dev_alloc(p, &q, sizeof(cf) * (size_t)p->S * (size_t)p->N) == PBH_OK) p->work2 = (cf*)q;
+        else (void)hipGetLastError();
+    }
+    return p->work2;
+}
+
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 
@@ -1069,6 +1089,17 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                           (colp_mode() != 0 && Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
+        cf* workB = nullptr;   // ping-pong schedule (oop_mode): column pass A -> B, row pass B -> A, column pass A -> B
+#ifndef PBH_F64
+        if (oop_mode() && !depth_mode() && P == 1 && colp && !in_sm && !out_sm && !fuse_radix && p->has_phase && row_phase_enabled() &&
+            p->phase16 && N2 == kTilePoints)
+            workB = ensure_work2(p);
+#endif
+        if (workB) {
+            cp1.ld = work;
+            cp1.ld_plane = N;
+            cp1.data = workB;
+        }
         if (in_sm && P == 1) {   // pass 1 reads the caller's series-major input directly: no de-interleave pass
             cp1.ld = in;
             cp1.ld_plane = io.in_pitch;
@@ -1126,10 +1157,19 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
             rpp.cP = chirp_split;
             rpp.phase16 = p->phase16;
+            if (workB) {
+                rpp.data = workB;
+                rpp.out = work;
+            }
             steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowp(N2, rpp, st); }});
         } else
 #endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
+        if (workB) {
+            cp3.ld = work;
+            cp3.ld_plane = N;
+            cp3.data = workB;
+        }
         if (out_sm && !tail.out && P == 1) {   // pass 3 writes the caller's series-major output directly, cropped
             cp3.ld = work;
             cp3.ld_plane = N;
@@ -1148,6 +1188,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 #ifndef PBH_F64
         }
 #endif
+        const cf* wlast = workB ? workB : work;   // where the last column pass left the time-ordered series
         const bool fuse_out = fuse_radix && !tail.out;   // the detect tail reads time-ordered planar data
         if (P > 1 && !fuse_out) {
             if (out_sm && !tail.out) {   // the inverse stage writes the caller's series-major output, cropped
@@ -1167,7 +1208,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             steps.push_back({"k_detect_planar", [=](hipStream_t st) {
                 if (nout <= 0) return (int)PBH_OK;
                 hipLaunchKernelGGL(k_detect_planar, dim3((unsigned)((nout + 3) / 4), (unsigned)nchan), dim3(256), 0, st,
-                                   (const cf*)work, tail.out, N, start, nout, nchan, npol, tail.mode, tail.nscrunch);
+                                   (const cf*)wlast, tail.out, N, start, nout, nchan, npol, tail.mode, tail.nscrunch);
                 HIPCHECK(hipGetLastError());
                 return (int)PBH_OK;
             }});
@@ -1180,7 +1221,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             const auto pp = io.part_ptr;
             const auto pr = io.part_row;
             steps.push_back({"k_reinterleave", [=](hipStream_t st) {
-                return launch_reinterleave_parts(work, out, start, stop, S, N, st, orow, pp, pr);
+                return launch_reinterleave_parts(wlast, out, start, stop, S, N, st, orow, pp, pr);
             }});
         }
     } else {
@@ -1917,7 +1958,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->sub) pbh_plan_destroy(p->sub);
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) hipFree(p->cf_in);
-    void* ptrs[] = {p->chirp_phase, p->work, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
+    void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm, p->mixR.wl, p->mixR.perm};
     for (void* q : ptrs)
         if (q) hipFree(q);

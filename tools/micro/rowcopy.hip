@@ -9,7 +9,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k(float2* data, int nrows) {
+__global__ __launch_bounds__(512) void k(float2* data, int nrows, float2* dst = nullptr) {
     const int t = threadIdx.x;
     if (MODE == 0) {
         for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
@@ -23,11 +23,12 @@ __global__ __launch_bounds__(512) void k(float2* data, int nrows) {
     } else if (MODE == 1) {
         for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
             float4* row = reinterpret_cast<float4*>(data + (size_t)r * 16384);
+            float4* wrow = reinterpret_cast<float4*>((dst ? dst : data) + (size_t)r * 16384);
             float4 v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = row[t + 512 * i];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { v[i].x += 1.f; row[t + 512 * i] = v[i]; }
+            for (int i = 0; i < 16; ++i) { v[i].x += 1.f; wrow[t + 512 * i] = v[i]; }
         }
     } else if (MODE == 2) {
         int r = blockIdx.x;
@@ -97,5 +98,18 @@ int main() {
             printf("%-44s grid %4d: %7.3f ms  %6.0f GB/s\n", names[mode], grid, ms, 2.0 * nrows * 16384 * 8 / ms * 1e-6);
             fflush(stdout);
         }
+    // round 3: the b128 form OUT OF PLACE (a second 2-GiB buffer receives the rows)
+    float2* d2; CK(hipMalloc(&d2, (size_t)nrows * 16384 * 8)); CK(hipMemset(d2, 0, (size_t)nrows * 16384 * 8));
+    for (int grid : {256, 512}) {
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 0, 0, d, nrows, d2);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 0, 0, d, nrows, d2);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 10;
+        printf("%-44s grid %4d: %7.3f ms  %6.0f GB/s\n", "b128, load all then store all, OUT OF PLACE", grid, ms, 2.0 * nrows * 16384 * 8 / ms * 1e-6);
+    }
     return 0;
 }
