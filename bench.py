@@ -101,6 +101,76 @@ def cpu_baseline():
     }
 
 
+def extra_configs4_share(steps=10):
+    """BASELINE configs[4], this GPU's share: 8 of the 64 channels of 6.25 MHz x 2 pol x 2^24 samples, DM 1000, fused
+    dedispersion + Stokes-I + 1024x time scrunch (60 B/sample algorithmic, the last pass writes ~0)."""
+    import torch
+    from pulsarbat_amd import _hip
+    from pulsarbat_amd.device import DeviceArray
+    import pulsarbat_amd as pb
+    from pulsarbat_amd import units as u
+    n, nchan_tot, nchan, npol, dmv = 1 << 24, 64, 8, 2, 1000.0
+    sr = BAND_HZ / nchan_tot
+    dm = pb.DM(dmv)
+    top = dm.sample_delay((CENTER_HZ + BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    bot = dm.sample_delay((CENTER_HZ - BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    start, stop = math.ceil(-min(0, top, bot)), n - math.ceil(max(0, top, bot))
+    freqs = (CENTER_HZ + sr * (np.arange(nchan_tot) + 0.5 - nchan_tot / 2))[:nchan]
+    g = torch.Generator(device="cuda").manual_seed(20260004)
+    x = DeviceArray(torch.view_as_complex(torch.randn((n, nchan, npol, 2), generator=g, device="cuda") * 0.7071))
+    with _hip.Plan(n, nchan, npol, start, stop) as plan:
+        plan.chirp_generate(dmv / 2.41e-4 * 1e12, 1 / sr, freqs, CENTER_HZ)
+        out = DeviceArray.empty(((stop - start) // 1024, nchan), np.float32)
+        for _ in range(3):
+            plan.dedisperse_detect(x, nscrunch=1024, mode="I", out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.dedisperse_detect(x, nscrunch=1024, mode="I", out=out)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    ns = float(n) * nchan * npol
+    return {"workload": "configs[4] per-GPU share: 2^24 x 8 of 64 chan x 2 pol, DM 1000, Stokes-I + 1024x scrunch, fused tail",
+            "ms_per_step": ms, "value": ns / ms / 1e3, "unit": "Msamples/s", "crop": [start, stop], "out_shape": list(out.shape),
+            "alg_bytes_per_sample": 60.0, "achieved_GBps": 60.0 * ns / ms / 1e6, "frac_of_8TBps": 60.0 * ns / ms / 1e6 / HBM_PEAK_GBPS}
+
+
+def extra_configs3_stream(total_log2=26):
+    """BASELINE configs[3], bounded: 2^26 samples x 8 x 2 (the full config is 2^28) streamed from pinned host memory in
+    2^22-sample chunks, overlap-save with every input row uploaded once (pbh_dedisperse_stream)."""
+    import torch
+    from pulsarbat_amd import _hip
+    import pulsarbat_amd as pb
+    from pulsarbat_amd import units as u
+    nchan, npol, n, total = NCHAN_PER_GPU, NPOL, 1 << 22, 1 << total_log2
+    sr = BAND_HZ / nchan
+    dm = pb.DM(DM)
+    top = dm.sample_delay((CENTER_HZ + BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    bot = dm.sample_delay((CENTER_HZ - BAND_HZ / 2) * u.Hz, CENTER_HZ * u.Hz, sr * u.Hz)
+    start, stop = math.ceil(-min(0, top, bot)), n - math.ceil(max(0, top, bot))
+    hop = stop - start
+    freqs = CENTER_HZ + sr * (np.arange(nchan) + 0.5 - nchan / 2)
+    blk = min(total, 1 << 24)   # one random block repeated with a different complex factor (randn of 8 GB takes a minute)
+    base = torch.randn((blk, nchan, npol, 2), dtype=torch.float32).numpy().view(np.complex64).reshape(blk, nchan, npol)
+    x = np.empty((total, nchan, npol), np.complex64)
+    for k in range(total // blk):
+        np.multiply(base, np.complex64(np.exp(0.37j * k) * (1 + 0.01 * k)), out=x[k * blk:(k + 1) * blk])
+    out = np.empty((((total - n) // hop + 1) * hop, nchan, npol), np.complex64)
+    out[::4096] = 0
+    with _hip.Plan(n, nchan, npol, start, stop) as plan:
+        plan.chirp_generate(DM / 2.41e-4 * 1e12, 1 / sr, freqs, CENTER_HZ)
+        y, ms = plan.dedisperse_stream(x, out=out)
+        st = plan.stream_stats()
+    return {"workload": "configs[3] bounded: 2^%d samples x 8 x 2 in 2^22-sample chunks, hop %d, %d chunks (full config: 2^28, "
+                        "430 chunks)" % (total_log2, hop, st["nchunk"]),
+            "ms_total": ms, "input_GB": x.nbytes / 1e9, "h2d_GB": st["h2d_bytes"] / 1e9, "d2h_GB": st["d2h_bytes"] / 1e9,
+            "h2d_GBps": st["h2d_GBps"], "d2h_GBps": st["d2h_GBps"], "kernel_ms": st["kernel_ms"],
+            "overlap_efficiency": st["overlap_efficiency"],
+            "input_Msamples_per_s": float(total) * nchan * npol / ms / 1e3,
+            "valid_Msamples_per_s": float(len(y)) * nchan * npol / ms / 1e3,
+            "note": "PCIe-bound (H2D and D2H of equal size run concurrently); never the headline value"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-series", action="store_true", help="skip the series-major secondary figure")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] extras (after the timed region)")
     ap.add_argument("--gather", nargs="?", const="all", default=None, choices=["all", "root"],
                     help="(multi-rank) also time one step that ends with the gather of the outputs by direct peer writes: "
                          "every rank gets the full band (all) or rank 0 does (root)")
@@ -296,10 +367,19 @@ def main():
                 "alg_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms}
     total_kernel_ms = sum(ms for _, ms in kern)
     path_bytes = info["alg_bytes_per_sample"] * samples_gpu  # 68 B/sample accounting figure
+    # what the five passes really move, and what that costs at the chip's own copy rate, measured now
+    moved = {"k_deinterleave": 16.0, "k_col_fwd": 16.0, "k_row_fused": 16.0 + 4.0 / NPOL, "k_col_inv": 8.0 + 8.0 * crop_frac,
+             "k_reinterleave": 16.0 * crop_frac, "k_small": 8.0 + 8.0 * crop_frac + 8.0 / NPOL}
+    moved_bytes = sum(moved[k] for k, _ in kern) * samples_gpu
+    copy_ms = _hip.copy_bench(1 << 31, iters=10, device=local_rank)
+    copy_gbps = 2.0 * (1 << 31) / copy_ms / 1e6
     path = {"alg_bytes_per_sample": info["alg_bytes_per_sample"],
             "achieved": path_bytes / (total_kernel_ms * 1e-3) / 1e9, "unit": "GB/s",
             "frac": path_bytes / (total_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "kernel_ms": {k: round(v, 4) for k, v in kern}, "kernel_ms_total": total_kernel_ms}
+            "kernel_ms": {k: round(v, 4) for k, v in kern}, "kernel_ms_total": total_kernel_ms,
+            "moved_bytes_per_step": moved_bytes, "copy_ceiling_GBps": copy_gbps,
+            "floor_ms": moved_bytes / copy_gbps / 1e6,
+            "floor_note": "bytes the five passes move / the float4 device copy rate measured in this run (pbh_copy_bench, 2 GiB)"}
 
     result = None
     if rank == 0:
@@ -324,6 +404,15 @@ def main():
             result["series_major_io"] = series_major
         if gather_ms is not None:
             result["step_with_gather_ms"] = {"mode": args.gather, "ms": gather_ms}
+        if world == 1 and not args.no_extras and args.log2n == 24:
+            del x, y, z_local
+            torch.cuda.empty_cache()
+            for key, fn in (("configs4_share", extra_configs4_share), ("configs3_stream", extra_configs3_stream)):
+                try:
+                    result[key] = fn()
+                except Exception as exc:   # extras never cost the main line
+                    result[key] = {"error": repr(exc)}
+                mark(f"extra {key} done")
         if world == 1 and not args.no_cpu:
             try:
                 result["cpu_baseline"] = cpu_baseline()

@@ -766,15 +766,28 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
     for (int a = 0; a < P; ++a) any |= ((int64_t)a * chunk + n0 < stop) && ((int64_t)a * chunk + n0 + TN > start);
     if (!any) return;
     vecr v[P][NV];
-#pragma unroll
-    for (int c = 0; c < P; ++c) {
+    // chunk c + 1 is requested while chunk c goes through LDS, and no further ahead: with every chunk's loads hoisted to the
+    // top (what the compiler does with the unrolled loop) 2 P NV vectors are live at once and the P = 7 kernel spilled 392 B/lane
+    vecr t[2][NV];
+    auto request = [&](int c, vecr (&dst)[NV]) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int pidx = threadIdx.x + 256 * j;
             const int s = pidx / (TN / VE), n = VE * (pidx % (TN / VE));
-            const vecr t = *reinterpret_cast<const vecr*>(in + (int64_t)s * plane + (int64_t)c * chunk + n0 + n);
+            dst[j] = *reinterpret_cast<const vecr*>(in + (int64_t)s * plane + (int64_t)c * chunk + n0 + n);
+        }
+    };
+    request(0, t[0]);
 #pragma unroll
-            for (int h = 0; h < VE; ++h) lds[s * LD + n + h] = make_cf(t[2 * h], t[2 * h + 1]);
+    for (int c = 0; c < P; ++c) {
+        if (c + 1 < P) request(c + 1, t[(c + 1) & 1]);
+        if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int pidx = threadIdx.x + 256 * j;
+            const int s = pidx / (TN / VE), n = VE * (pidx % (TN / VE));
+#pragma unroll
+            for (int h = 0; h < VE; ++h) lds[s * LD + n + h] = make_cf(t[c & 1][j][2 * h], t[c & 1][j][2 * h + 1]);
         }
         __syncthreads();
 #pragma unroll
@@ -807,6 +820,9 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
                 v[a][j][2 * h] = x[a].x;
                 v[a][j][2 * h + 1] = x[a].y;
             }
+            // one DFT at a time: left alone, the scheduler interleaves all NV * VE of them (the odd ones are O(P^2) products
+            // with literal roots) and the float32 kernel at P = 7 spilled 392 B/lane
+            if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -819,6 +835,7 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
             if (t >= start && t < stop)
                 *reinterpret_cast<vecr*>(out + (t - start) * S + (e % S)) = v[a][j];
         }
+        if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);   // (one chunk's addresses at a time)
     }
 }
 
@@ -1286,10 +1303,17 @@ __global__ __launch_bounds__(256) void k_pol_basis(const cf* __restrict__ in, cf
 
 #ifndef PBH_F64
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
+// One contiguous 16-KiB chunk per workgroup, four 16-byte loads in flight per lane: the fastest plain copy on MI355X
+// (tools/micro/membench.hip, profiles/r01_membench.txt: 5.93 TB/s; a grid-stride loop reaches 4.7-5.0, hipMemcpyDtoD 5.3).
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = in[i];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) v[u] = in[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) out[base + u * 256] = v[u];
 }
 
 #endif  // !PBH_F64

@@ -343,8 +343,10 @@ static int row_grid() {
         int v = e ? atoi(e) : 0;
         if (v > 0) return v;
         int dev = 0, cus = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            cus = 256;   // MI355X
+        }
         return cus;  // one persistent workgroup per CU (LDS admits one)
     }();
     return g;
@@ -1287,8 +1289,8 @@ thread_local Bounce g_bounce[16];
 void release_bounce_buffers() {   // pbh_trim: 16 MiB of pinned memory per (thread, device) that used a host transfer
     for (Bounce& b : g_bounce)
         for (int i = 0; i < 2; ++i) {
-            if (b.ev[i]) { hipEventSynchronize(b.ev[i]); hipEventDestroy(b.ev[i]); b.ev[i] = nullptr; }
-            if (b.buf[i]) { hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
+            if (b.ev[i]) { (void)hipEventSynchronize(b.ev[i]); (void)hipEventDestroy(b.ev[i]); b.ev[i] = nullptr; }
+            if (b.buf[i]) { (void)hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
         }
 }
 Bounce* bounce_for_current_device() {
@@ -1525,8 +1527,8 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
     hipStream_t st = (hipStream_t)hip_stream;
     void *sraw = nullptr, *sconj = nullptr;
     auto cleanup = [&] {
-        if (sraw) hipFree(sraw);
-        if (sconj) hipFree(sconj);
+        if (sraw) (void)hipFree(sraw);
+        if (sconj) (void)hipFree(sconj);
     };
     const unsigned char* draw = (const unsigned char*)raw;
     int64_t skip = 0;
@@ -1567,7 +1569,7 @@ int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, 
 static int ensure_stage(pbh_plan* p, void** buf, size_t* have, size_t need) {
     if (*have >= need) return PBH_OK;
     if (*buf) {
-        hipFree(*buf);
+        (void)hipFree(*buf);
         p->owned_bytes -= (int64_t)*have;
         *buf = nullptr;
         *have = 0;
@@ -1792,9 +1794,9 @@ static int rebuild_circular_filter(pbh_plan* p) {
             rc = spectrum_in_plan_order(q, nchan, p->cf_in, st);
         }
     }
-    hipStreamSynchronize(st);
-    hipFree(nat);
-    if (hh) hipFree(hh);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, "circular filter: stream synchronisation failed");
+    (void)hipFree(nat);
+    if (hh) (void)hipFree(hh);
     if (rc == PBH_OK) {
         q->has_chirp = true;
         q->has_phase = false;
@@ -1954,14 +1956,14 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
 
 int pbh_plan_destroy(pbh_plan* p) {
     if (!p) return PBH_OK;
-    hipSetDevice(p->device);
+    (void)hipSetDevice(p->device);   // (a failure shows in the frees below, which are best effort)
     if (p->sub) pbh_plan_destroy(p->sub);
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
-    if (p->cf_in) hipFree(p->cf_in);
+    if (p->cf_in) (void)hipFree(p->cf_in);
     void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm, p->mixR.wl, p->mixR.perm};
     for (void* q : ptrs)
-        if (q) hipFree(q);
+        if (q) (void)hipFree(q);
     delete p;
     return PBH_OK;
 }
@@ -2135,7 +2137,7 @@ static int with_device_doubles(const double* host, int n, hipStream_t st, double
     PBHCHECK(dev_alloc(nullptr, (void**)dev, sizeof(double) * (size_t)n));
     hipError_t e = hipMemcpyAsync(*dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) {
-        hipFree(*dev);
+        (void)hipFree(*dev);
         return fail(PBH_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
     }
     return PBH_OK;
@@ -2155,8 +2157,9 @@ int pbh_mix(int device, void* hip_stream, int /*dtype*/, const void* in_dev, voi
     hipLaunchKernelGGL(k_mix, dim3((unsigned)blocks), dim3(256), 0, st, (const cf*)in_dev, (cf*)out_dev, (const double*)d,
                        nsample, nseries);
     hipError_t e = hipGetLastError();
-    hipStreamSynchronize(st);
-    hipFree(d);
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
+    (void)hipFree(d);
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_mix: ") + hipGetErrorString(e));
     return PBH_OK;
 }
@@ -2182,8 +2185,9 @@ int pbh_zero_edges(int device, void* hip_stream, int /*dtype*/, void* data_dev, 
     hipLaunchKernelGGL(k_zero_edges, dim3((unsigned)blocks), dim3(256), 0, st, (cf*)data_dev, (const double*)d, nsample,
                        nseries, maxrows);
     hipError_t e = hipGetLastError();
-    hipStreamSynchronize(st);
-    hipFree(d);
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
+    (void)hipFree(d);
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("k_zero_edges: ") + hipGetErrorString(e));
     return PBH_OK;
 }
@@ -2279,8 +2283,8 @@ static int incoherent_two_pass(hipStream_t st, const void* in_dev, void* out_dev
         if (hipGetLastError() != hipSuccess) rc = fail(PBH_ERR_HIP, "pbh_incoherent: de-interleave launch failed");
     }
     if (rc == PBH_OK) rc = launch_reinterleave(tmp, (cf*)out_dev, 0, nout, S, plane, st, 0, dd);
-    hipFreeAsync(tmp, st);
-    if (dd) hipFreeAsync(dd, st);
+    (void)hipFreeAsync(tmp, st);
+    if (dd) (void)hipFreeAsync(dd, st);
     return rc;
 }
 
@@ -2372,12 +2376,12 @@ int pbh_chirp_function(int device, void* hip_stream, double coeff_hz, int64_t ns
     PBHCHECK(dev_alloc(nullptr, (void**)&dfreq, sizeof(double)));
     int rc = PBH_OK;
     if (loc == PBH_HOST && (rc = dev_alloc(nullptr, (void**)&dbuf, bytes)) != PBH_OK) {
-        hipFree(dfreq);
+        (void)hipFree(dfreq);
         return rc;
     }
     auto cleanup = [&]() {
-        hipFree(dfreq);
-        if (loc == PBH_HOST) hipFree(dbuf);
+        (void)hipFree(dfreq);
+        if (loc == PBH_HOST) (void)hipFree(dbuf);
     };
     hipError_t e = hipMemcpyAsync(dfreq, &center_freq_hz, sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -2692,14 +2696,14 @@ int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const 
     if (in_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &sin, in_bytes)) != PBH_OK) return rc;
         if (xfer_h2d(sin, in_c64, in_bytes, st) != hipSuccess) {
-            hipFree(sin);
+            (void)hipFree(sin);
             return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
         }
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &sout, out_bytes ? out_bytes : 16)) != PBH_OK) {
-            if (sin) hipFree(sin);
+            if (sin) (void)hipFree(sin);
             return rc;
         }
         dout = (real*)sout;
@@ -2712,8 +2716,8 @@ int pbh_detect(int device, void* hip_stream, int /*dtype: this build's*/, const 
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
     }
-    if (sin) hipFree(sin);
-    if (sout) hipFree(sout);
+    if (sin) (void)hipFree(sin);
+    if (sout) (void)hipFree(sout);
     if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_detect: ") + hipGetErrorString(e));
     return PBH_OK;
@@ -2750,8 +2754,8 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
         int rc = run_steps(steps, p->stream);
         if (rc == PBH_OK)
             rc = launch_detect(p->stream, (const cf*)mid, (real*)dout, nout, p->nchan, p->npol, mode, nscrunch);
-        hipStreamSynchronize(p->stream);
-        hipFree(mid);
+        if (hipStreamSynchronize(p->stream) != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, "detect: stream synchronisation failed");
+        (void)hipFree(mid);
         PBHCHECK(rc);
     }
     if (out_loc == PBH_HOST && out_bytes)
@@ -2813,7 +2817,7 @@ static int standalone_twiddles(int device, cf** out) {
         cf* t = nullptr;
         PBHCHECK(dev_alloc(nullptr, (void**)&t, sizeof(cf) * kTwTable));
         if (hipMemcpy(t, h.data(), sizeof(cf) * kTwTable, hipMemcpyHostToDevice) != hipSuccess) {
-            hipFree(t);
+            (void)hipFree(t);
             return fail(PBH_ERR_HIP, "hipMemcpy(twiddles) failed");
         }
         g_tw_table[device] = t;
@@ -2836,8 +2840,8 @@ int pbh_trim(void) {
     for (int d = 0; d < 16; ++d)
         if (g_tw_table[d]) {   // freed on the device that owns it, after its work has drained
             if (hipSetDevice(d) == hipSuccess) {
-                hipDeviceSynchronize();
-                hipFree(g_tw_table[d]);
+                (void)hipDeviceSynchronize();   // best effort: the table is freed either way
+                (void)hipFree(g_tw_table[d]);
             }
             g_tw_table[d] = nullptr;
         }
@@ -2846,7 +2850,7 @@ int pbh_trim(void) {
         if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
         (void)hipGetLastError();
     }
-    if (have_cur) hipSetDevice(cur);
+    if (have_cur) (void)hipSetDevice(cur);
     release_bounce_buffers();
     return PBH_OK;
 }
@@ -3068,14 +3072,14 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &sin, bytes));
         if (xfer_h2d(sin, in_c64, bytes, st) != hipSuccess) {
-            hipFree(sin);
+            (void)hipFree(sin);
             return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
         }
         din = (const cf*)sin;
     }
     if (out_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &sout, bytes)) != PBH_OK) {
-            if (sin) hipFree(sin);
+            if (sin) (void)hipFree(sin);
             return rc;
         }
         dout = (cf*)sout;
@@ -3094,8 +3098,8 @@ int pbh_fft_c2c(int device, void* hip_stream, int /*dtype: this build's*/, const
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
     }
-    if (sin) hipFree(sin);
-    if (sout) hipFree(sout);
+    if (sin) (void)hipFree(sin);
+    if (sout) (void)hipFree(sout);
     if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_fft_c2c: ") + hipGetErrorString(e));
     return PBH_OK;
@@ -3120,14 +3124,14 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
     if (in_loc == PBH_HOST) {
         PBHCHECK(dev_alloc(nullptr, &stg_in, bytes));
         if (xfer_h2d(stg_in, in, bytes, st) != hipSuccess) {
-            hipFree(stg_in);
+            (void)hipFree(stg_in);
             return fail(PBH_ERR_HIP, "host-to-device copy of the input failed");
         }
         din = (const cf*)stg_in;
     }
     if (out_loc == PBH_HOST) {
         if ((rc = dev_alloc(nullptr, &stg_out, bytes)) != PBH_OK) {
-            if (stg_in) hipFree(stg_in);
+            if (stg_in) (void)hipFree(stg_in);
             return rc;
         }
         dout = (cf*)stg_out;
@@ -3219,8 +3223,8 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
         hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
     }
-    if (stg_in) hipFree(stg_in);
-    if (stg_out) hipFree(stg_out);
+    if (stg_in) (void)hipFree(stg_in);
+    if (stg_out) (void)hipFree(stg_out);
     if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("pbh_stft: ") + hipGetErrorString(e));
     return PBH_OK;
@@ -3597,20 +3601,24 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
     for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
     std::vector<double> acc(nk, 0.0);
     int rc = PBH_OK;
+    // every event call is checked: these durations are what bench.py's `roofline` is computed from
+    auto evok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string("profile: ") + what + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
     for (int it = 0; it < iters && rc == PBH_OK; ++it) {
-        hipEventRecord(ev[0], p->stream);
+        evok(hipEventRecord(ev[0], p->stream), "hipEventRecord");
         for (int k = 0; k < nk && rc == PBH_OK; ++k) {
             rc = steps[k].launch(p->stream);
-            hipEventRecord(ev[k + 1], p->stream);
+            if (rc == PBH_OK) evok(hipEventRecord(ev[k + 1], p->stream), "hipEventRecord");
         }
-        if (hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(PBH_ERR_HIP, "profile: stream sync failed");
+        evok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
         for (int k = 0; k < nk && rc == PBH_OK; ++k) {
             float ms = 0.f;
-            hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-            acc[k] += ms;
+            if (evok(hipEventElapsedTime(&ms, ev[k], ev[k + 1]), "hipEventElapsedTime")) acc[k] += ms;
         }
     }
-    for (auto& e : ev) hipEventDestroy(e);
+    for (auto& e : ev) (void)hipEventDestroy(e);
     PBHCHECK(rc);
     for (int j = 0; j < (int)uniq.size(); ++j) {
         ms_per_kernel[j] = 0.f;
@@ -3626,28 +3634,32 @@ int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
     if (!ms_mean || bytes < 16 || iters <= 0) return fail(PBH_ERR_INVALID, "bad argument");
     HIPCHECK(hipSetDevice(device));
     void *a = nullptr, *b = nullptr;
-    PBHCHECK(dev_alloc(nullptr, &a, (size_t)bytes));
-    if (dev_alloc(nullptr, &b, (size_t)bytes) != PBH_OK) {
-        hipFree(a);
-        return PBH_ERR_NOMEM;
-    }
-    hipMemset(a, 1, (size_t)bytes);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    const int64_t n = bytes / 16;
-    hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
-    hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
-    hipEventRecord(e1, 0);
-    hipError_t e = hipEventSynchronize(e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = dev_alloc(nullptr, &a, (size_t)bytes);
+    if (rc == PBH_OK) rc = dev_alloc(nullptr, &b, (size_t)bytes);
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return x == hipSuccess; };
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(a);
-    hipFree(b);
+    if (rc == PBH_OK) {
+        const int64_t n = bytes / 16;
+        const unsigned grid = (unsigned)((n + 1023) / 1024);
+        ok(hipMemset(a, 1, (size_t)bytes));
+        ok(hipEventCreate(&e0));
+        ok(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+        ok(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i)
+            hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+        ok(hipGetLastError());
+        ok(hipEventRecord(e1, 0));
+        ok(hipEventSynchronize(e1));
+        if (e == hipSuccess) ok(hipEventElapsedTime(&ms, e0, e1));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc != PBH_OK) return rc;
     if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("copy bench: ") + hipGetErrorString(e));
     *ms_mean = ms / iters;
     return PBH_OK;

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_json_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-series"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-series", "--no-extras"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -31,3 +31,6 @@ def test_bench_json_line():
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0.3 < roof["frac"] < 1.0
+    # the path figure says what the five passes move and what that costs at the copy rate measured in the same run
+    path = j["path_roofline"]
+    assert 0 < path["floor_ms"] < path["kernel_ms_total"] and 3000 < path["copy_ceiling_GBps"] < 8000
