@@ -609,12 +609,13 @@ template <int S, bool PITCHED = false, bool SHIFTED = false>
 __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
                                                          int64_t start, int64_t plane, int64_t opitch,
                                                          const int64_t* __restrict__ dly = nullptr) {
-    // LDS image as in k_deinterleave_p2; here the interleaved side READS 8 bytes per lane in groups of 32 lanes (64 / S time
-    // samples of S / 2 even series), so the rotation is c = (s >> 1)(64 / S), and the planar side writes 16 aligned bytes.
+    // LDS image as in k_deinterleave_p2 (same rotation): the interleaved side's two reads of a lane, series s and s + 1 at the
+    // same rotated index, are exactly TN slots apart and become ONE ds_read2st64_b64, whose accesses go in 16-lane groups like
+    // the writes there; the planar side writes 16 aligned bytes.
     constexpr bool SWZ = S >= 2 && S <= 16;
     constexpr int TN = kTrElems / S, LD = SWZ ? TN : TN + 1, NV = kTrElems / 2 / 256;
     __shared__ __attribute__((aligned(16))) cf lds[S * LD];
-    auto slot = [](int s, int n) { return SWZ ? s * TN + ((n + (s >> 1) * (64 / (SWZ ? S : 64))) & (TN - 1)) : s * LD + n; };
+    auto slot = [](int s, int n) { return SWZ ? s * TN + ((n + (s >> 1) * (32 / (SWZ ? S : 32))) & (TN - 1)) : s * LD + n; };
     const int64_t t0 = start + (int64_t)blockIdx.x * TN;
     cf a[NV], b[NV];
 #pragma unroll
@@ -765,6 +766,11 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
 #pragma unroll
     for (int a = 0; a < P; ++a) any |= ((int64_t)a * chunk + n0 < stop) && ((int64_t)a * chunk + n0 + TN > start);
     if (!any) return;
+    // the stage's twiddles first: sincospi in float64 needs ~100 registers of its own, which must not coincide with the P * NV
+    // vectors of the loaded tile (computed after the loads, as before, the P = 7 kernel spilled 392 B/lane)
+    cf tw[P];
+    radix_twiddles<P>(tw, n0 / N2, N1, +1);
+    if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);
     vecr v[P][NV];
     // chunk c + 1 is requested while chunk c goes through LDS, and no further ahead: with every chunk's loads hoisted to the
     // top (what the compiler does with the unrolled loop) 2 P NV vectors are live at once and the P = 7 kernel spilled 392 B/lane
@@ -803,8 +809,6 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
         }
         __syncthreads();
     }
-    cf tw[P];
-    radix_twiddles<P>(tw, n0 / N2, N1, +1);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
 #pragma unroll
