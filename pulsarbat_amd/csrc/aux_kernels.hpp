@@ -829,17 +829,21 @@ __global__ __launch_bounds__(256) void k_reint_radix(const cf* __restrict__ in, 
             if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // Cropped samples are dropped by an out-of-range buffer offset, not by a branch: with `if (in range) store` the compiler sank
+    // the whole radix stage INTO the 28 branches of the P = 7 kernel (a copy of the DFT per store) and spilled 392 B/lane.
+    // (The descriptor's base may lie before `out` when a chunk starts inside the cropped head: only in-range offsets are used.)
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         const int64_t t0 = (int64_t)a * chunk + n0;
+        const rsrc_t ro = make_rsrc(out + (t0 - start) * S, (uint32_t)(E * sizeof(cf)));
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int e = VE * (threadIdx.x + 256 * j);
             const int64_t t = t0 + e / S;
-            if (t >= start && t < stop)
-                *reinterpret_cast<vecr*>(out + (t - start) * S + (e % S)) = v[a][j];
+            union { vecr r; u32x4 u; } x;
+            x.r = v[a][j];
+            __builtin_amdgcn_raw_buffer_store_b128(x.u, ro, (t >= start && t < stop) ? e * (int)sizeof(cf) : (int)0x80000000, 0, 0);
         }
-        if constexpr (P >= 5) __builtin_amdgcn_sched_barrier(0);   // (one chunk's addresses at a time)
     }
 }
 

@@ -1279,26 +1279,52 @@ template <int M, int R>
 __global__ __launch_bounds__(kTilePoints / R) void k_seg_pair(SegPairParams p) {
     static_assert(M == kTilePoints, "k_seg_pair: one segment of one series per tile");
     constexpr int MR = M / R;
-    typedef real vec4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     const int tau = threadIdx.x;
     const int q = 2 * blockIdx.x;            // first series of the pair
     const int c = q / p.E, e = q - c * p.E;
-    const int64_t seg = (int64_t)blockIdx.y * M * p.S;   // segments are consecutive (M, S) blocks on both sides
-    // element offsets of row (tau + i*MR): time-ordered (t*S + q); channelised ((c*M + r)*E + e)
-    const int64_t t_off = seg + (int64_t)tau * p.S + q, t_step = (int64_t)MR * p.S;
-    const int64_t c_off = seg + ((int64_t)c * M + tau) * p.E + e, c_step = (int64_t)MR * p.E;
+    // segments are consecutive (M, S) blocks on both sides: one buffer descriptor per side and segment (the host checks that a
+    // segment stays below 2 GiB), a per-lane byte offset and scalar row steps -- per-row 64-bit addresses cost this kernel
+    // 252 B/lane of scratch (348 in the float64 build)
+    const int64_t seg = (int64_t)blockIdx.y * M * p.S;
+    const uint32_t span = (uint32_t)((int64_t)M * p.S * (int64_t)sizeof(cf));
+    const rsrc_t ri = make_rsrc(p.in + seg, span), ro = make_rsrc(p.out + seg, span);
+    // byte offsets of row (tau + i*MR): time-ordered (t*S + q); channelised ((c*M + r)*E + e)
+    const int t_v = (tau * p.S + q) * (int)sizeof(cf), t_s = MR * p.S * (int)sizeof(cf);
+    const int c_v = ((c * M + tau) * p.E + e) * (int)sizeof(cf), c_s = MR * p.E * (int)sizeof(cf);
+    auto load2 = [&](int voff, int soff, cf& x, cf& y) {
+        if constexpr (sizeof(cf) == 8) {
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ri, voff, soff, 0);
+            union { u32x4 u; real r[4]; } t;
+            t.u = u;
+            x = make_cf(t.r[0], t.r[1]);
+            y = make_cf(t.r[2], t.r[3]);
+        } else {
+            x = buf_load(ri, voff, soff);
+            y = buf_load(ri, voff + (int)sizeof(cf), soff);
+        }
+    };
+    auto store2 = [&](int voff, int soff, cf x, cf y) {
+        if constexpr (sizeof(cf) == 8) {
+            union { u32x4 u; real r[4]; } t;
+            t.r[0] = x.x; t.r[1] = x.y; t.r[2] = y.x; t.r[3] = y.y;
+            __builtin_amdgcn_raw_buffer_store_b128(t.u, ro, voff, soff, 0);
+        } else {
+            buf_store(ro, voff, soff, x);
+            buf_store(ro, voff + (int)sizeof(cf), soff, y);
+        }
+    };
 
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
     cf a[R], b[R];
+    if (p.inverse) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const cf* src = p.inverse ? p.in + c_off + (i ^ (R / 2)) * c_step : p.in + t_off + i * t_step;   // ifftshift
-        const vec4 x = *reinterpret_cast<const vec4*>(src);
-        a[i] = make_cf(x[0], x[1]);
-        b[i] = make_cf(x[2], x[3]);
+        for (int i = 0; i < R; ++i) load2(c_v, (i ^ (R / 2)) * c_s, a[i], b[i]);   // ifftshift
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) load2(t_v, i * t_s, a[i], b[i]);
     }
     // (the seeds are laundered before each transform: otherwise the twiddle-power trees of the first are kept
     //  alive for the second, ~140 VGPRs on top of the 128 the pair occupies)
@@ -1316,15 +1342,14 @@ __global__ __launch_bounds__(kTilePoints / R) void k_seg_pair(SegPairParams p) {
         launder_all(w, seeds);
         fft_tile<M, 1, R, -1, 1, true>(b, lds, tau, 0, w);
     }
+    if (p.inverse) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        cf* dst = p.inverse ? p.out + t_off + i * t_step : p.out + c_off + (i ^ (R / 2)) * c_step;   // fftshift
-        vec4 x;
-        x[0] = a[i].x * p.scale;
-        x[1] = a[i].y * p.scale;
-        x[2] = b[i].x * p.scale;
-        x[3] = b[i].y * p.scale;
-        *reinterpret_cast<vec4*>(dst) = x;
+        for (int i = 0; i < R; ++i)
+            store2(t_v, i * t_s, make_cf(a[i].x * p.scale, a[i].y * p.scale), make_cf(b[i].x * p.scale, b[i].y * p.scale));
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i)   // fftshift
+            store2(c_v, (i ^ (R / 2)) * c_s, make_cf(a[i].x * p.scale, a[i].y * p.scale), make_cf(b[i].x * p.scale, b[i].y * p.scale));
     }
 }
 

@@ -3143,7 +3143,7 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
     } else if (is_pow2(n) && n >= PBH_R && n <= kTilePoints) {
         cf* tw = nullptr;
         rc = standalone_twiddles(device, &tw);
-        if (rc == PBH_OK && n == kTilePoints && inner % 2 == 0 && stft_pair_enabled()) {
+        if (rc == PBH_OK && n == kTilePoints && inner % 2 == 0 && stft_pair_enabled() && n * S * (int64_t)sizeof(cf) < (1LL << 31)) {
             // one segment of one series fills a tile: a workgroup takes both series of a pair (k_seg_pair)
             auto kern = k_seg_pair<kTilePoints, PBH_R>;
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tile_bytes<true>()) != hipSuccess)
