@@ -335,6 +335,17 @@ int pbh_stft(int device, void* hip_stream, int dtype, const void* in, void* out,
 int pbh_stft_dedisperse(pbh_plan* plan, const void* in_dev, int nperseg, int nchan_in, void* out_dev, int out_layout,
                         int64_t out_pitch);
 
+/* The way back: coherent_dedispersion followed by contrib.istft (transforms/dedispersion.py:118-133, then
+ * pulsarbat/contrib/misc.py:58-93) in one call.  `plan` is again the dedispersion plan of the CHANNELISED block
+ * (nsample = nseg, nchan = nchan_out*nperseg, npol = inner); in_dev the device-resident channelised block, sample-major
+ * or series-major (in_layout, in_pitch as in pbh_dedisperse_layout); out_dev the C-contiguous
+ * ((stop-start)*nperseg, nchan_out, inner) time series.  Where the geometry allows (complex64, nperseg = 2^m in
+ * [32, 1024], nseg beyond one tile, at least 64-byte output runs per tile) the dedispersion's last column pass leaves its
+ * cropped result series-major in the plan's staging buffer and the synthesis kernel reads that: the channelised result is
+ * neither re-interleaved nor read back.  Other geometries run the two steps.  Asynchronous on the plan's stream.      */
+int pbh_dedisperse_istft(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch, int nperseg, int nchan_out,
+                         void* out_dev);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Runs the plan's kernel sequence `iters` times on device-resident in/out with hipEvents between the
  * kernels (on the plan's stream) and returns the mean milliseconds of each kernel.                    */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pbh_dedisperse_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_float)]),
+    "pbh_dedisperse_istft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "pbh_stream_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pbh_dedisperse_stream_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_RawLayout), C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int64),
@@ -421,6 +422,29 @@ class Plan:
             raise ValueError("out_layout must be 'sample' or 'series'")
         _check(lib().pbh_stft_dedisperse(self._h, C.c_void_p(x.contiguous().data_ptr()), nperseg, int(nchan_in),
                                          C.c_void_p(out.raw_ptr()), int(out_layout == "series"), int(pitch)))
+        return out
+
+    def dedisperse_istft(self, x, nperseg):
+        """``istft(coherent_dedispersion(x), nperseg)`` in one call (``pbh_dedisperse_istft``): ``x`` is the device-resident
+        channelised block ``(nseg, nchan_out*nperseg, ...)`` this plan dedisperses (sample-major or series-major), the
+        result the ``((stop-start)*nperseg, nchan_out, ...)`` time series."""
+        from .device import DeviceArray
+        if not isinstance(x, DeviceArray):
+            raise TypeError("dedisperse_istft takes a device-resident input")
+        nperseg = int(nperseg)
+        self._check_in(x)
+        if nperseg < 1 or self.nchan % nperseg:
+            raise ValueError(f"{self.nchan} channels are not a whole number of {nperseg}-bin channels")
+        nchan_out = self.nchan // nperseg
+        self._sync_stream()
+        out = DeviceArray.empty((self.nout * nperseg, nchan_out) + tuple(x.shape[2:]), self.dtype, device=self.device)
+        if self.nout == 0:
+            return out
+        pitch = None if x.tensor.is_contiguous() else x.series_major_pitch()
+        if pitch is None:
+            x = x.contiguous()
+        _check(lib().pbh_dedisperse_istft(self._h, C.c_void_p(x.raw_ptr()), int(pitch is not None), int(pitch or 0), nperseg,
+                                          int(nchan_out), C.c_void_p(out.raw_ptr())))
         return out
 
     def dedisperse_mix(self, x, ft):

@@ -16,7 +16,7 @@ from .. import _hip
 from ..core import BasebandSignal
 from ..device import DeviceArray
 
-__all__ = ["stft", "istft", "stft_dedisperse"]
+__all__ = ["stft", "istft", "stft_dedisperse", "dedisperse_istft"]
 
 
 def _data(z):
@@ -91,3 +91,27 @@ def stft_dedisperse(z, DM, /, *, nperseg=256, ref_freq=None, variant="auto"):
     if z.start_time is not None:
         kw["start_time"] = z.start_time + start / meta.sample_rate
     return type(z).like(z, y, sample_rate=meta.sample_rate, freq_align=falign, **kw)
+
+
+def dedisperse_istft(z, DM, /, *, nperseg=256, ref_freq=None, chirp=None, variant="auto"):
+    """``istft(coherent_dedispersion(z, DM, ref_freq=ref_freq, chirp=chirp), nperseg=nperseg)`` -- the way back from a
+    channelised block (transforms/dedispersion.py:118-133 followed by misc.py:58-93) -- as ONE call of the HIP library
+    (``pbh_dedisperse_istft``) for device-resident complex64 signals: the dedispersion's last pass leaves its cropped
+    result series-major and the synthesis filterbank reads that, so the channelised result is neither re-interleaved into
+    the reference layout nor read back.  Same result, metadata included, as the two calls; signals on the host, user
+    chirps and other dtypes run the two steps one after the other."""
+    from ..transforms.dedispersion import _crop_bounds, _plan_for, coherent_dedispersion
+    if not isinstance(z, BasebandSignal):
+        raise ValueError("z must be a BasebandSignal.")
+    nperseg = int(nperseg)
+    if (not isinstance(z.data, DeviceArray) or z.data.dtype != np.complex64 or chirp is not None or nperseg < 2
+            or z.shape[1] % nperseg):
+        return istft(coherent_dedispersion(z, DM, ref_freq=ref_freq, chirp=chirp, variant=variant), nperseg=nperseg)
+    ref = z.center_freq if ref_freq is None else ref_freq
+    start, stop = _crop_bounds(z, DM, ref)
+    plan, _ = _plan_for(z, DM, ref, (start, stop), variant=variant)
+    y = plan.dedisperse_istft(z.data, nperseg)
+    kw = {}
+    if z.start_time is not None:
+        kw["start_time"] = z.start_time + start / z.sample_rate
+    return type(z).like(z, y, sample_rate=z.sample_rate * nperseg, freq_align="center", **kw)

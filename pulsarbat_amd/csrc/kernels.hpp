@@ -1261,6 +1261,76 @@ __global__ __launch_bounds__(kTilePoints / R) void k_stft_planar(StftPlanarParam
     }
 }
 
+// ---- contrib.istft fed series-major: the synthesis filterbank behind coherent_dedispersion -------------------------
+// coherent_dedispersion -> istft is the way back from a channelised block (pulsarbat/contrib/misc.py:58-93 after
+// transforms/dedispersion.py:125).  The dedispersion's last column pass can leave its cropped result series-major
+// (series' q' = (c*M + shifted k)*E + e at q'*plane, time = segment index); this kernel reads THAT -- the mirror of
+// k_stft_planar -- so the channelised result is neither re-interleaved into the reference layout nor read back from it.
+// A tile is M (bins) x G (consecutive segments) x SB (series of the output): lanes run along the segment index on the
+// load side (G >= 16: runs of >= 128 bytes), the values take one trip through LDS (rows padded to G + 1 slots: the column
+// reads are then conflict-free) into the interleaved-column order of the tile FFT, and the inverse transform's outputs
+// are stored as rows of SB series.  x M (the reference's x *= nperseg) and ifft's 1/M cancel: the transform is unscaled.
+struct IstftPlanarParams {
+    const cf* in;      // planar: series' q' = (c*M + (k ^ M/2))*E + e at q'*plane + segment
+    cf* out;           // (nseg*M, S) sample-major
+    const cf* tw16k;
+    int64_t plane;
+    int64_t nseg;      // segments that exist from this launch's first one on (the last tile may be short)
+    int S, E;          // series of the output (nchan_out*E), inner elements per channel
+    int SB, G;         // series per tile, segments per tile (SB*G = tile/M)
+};
+
+template <int M, int R>
+__global__ __launch_bounds__(kTilePoints / R) void k_istft_planar(IstftPlanarParams p) {
+    constexpr int F = kTilePoints / M;
+    constexpr bool PAD = F < 16;
+    constexpr int MR = M / R;
+    constexpr int NT = kTilePoints / R;      // threads
+    static_assert(F <= NT && F >= 16, "k_istft_planar: segment length out of range for this tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int f = tid % F, tau = tid / F;
+    const int j = f % p.SB, sl = f / p.SB;
+    const int q0 = blockIdx.x * p.SB;
+    const int64_t g0 = (int64_t)blockIdx.y * p.G;
+    const int GP = p.G + 1;                  // padded row of the staging image
+
+    cf w[tw_seeds_or1(M, R)];
+    load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+    {
+        // thread tid, round i: bin k = k0 + i*NT/F of series jj, segment ss (ss fastest across lanes)
+        const int ss = tid % p.G, rest = tid / p.G;
+        const int jj = rest % p.SB, k0 = rest / p.SB;
+        const int q = q0 + jj;
+        const int c = q / p.E, e = q - c * p.E;
+        const bool have = g0 + ss < p.nseg;
+        const cf* base = p.in + ((int64_t)c * M * p.E + e) * p.plane + g0 + ss;
+        const int64_t kstep = (int64_t)p.E * p.plane;
+        cf x[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int k = k0 + i * (NT / F);
+            x[i] = have ? base[(int64_t)(k ^ (M / 2)) * kstep] : make_cf(0, 0);   // ifftshift
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) lds[((k0 + i * (NT / F)) * p.SB + jj) * GP + ss] = x[i];
+    }
+    __syncthreads();
+    cf v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = lds[((tau + i * MR) * p.SB + j) * GP + sl];
+    __syncthreads();
+    fft_tile<M, 1, R, +1, F, PAD>(v, lds, tau, f, w);
+    // rows m = tau + i*MR of segment g0 + sl, series q0 + j: SB series of a time sample are adjacent.  Segments beyond the
+    // end are dropped by an out-of-range offset (a branch around the stores invites the compiler to sink the transform into it)
+    const rsrc_t ro = make_rsrc(p.out + g0 * M * (int64_t)p.S, (uint32_t)(((int64_t)p.G * M * p.S) * (int64_t)sizeof(cf)));
+    const int voff = (g0 + sl < p.nseg) ? (int)((((int64_t)sl * M + tau) * p.S + q0 + j) * (int64_t)sizeof(cf)) : (int)0x80000000;
+    const int step = MR * p.S * (int)sizeof(cf);
+#pragma unroll
+    for (int i = 0; i < R; ++i) buf_store(ro, voff, i * step, v[i]);
+}
+
 // ---- contrib.stft / istft with one segment per tile (nperseg = 2^tile) and an even number of inner elements ----
 // k_small would give each of the two polarisations of a channel to a different workgroup: 8-byte pieces at a
 // 16-byte stride on both sides (2.0 TB/s).  Here a workgroup transforms BOTH series of a pair: it loads 16 or 32

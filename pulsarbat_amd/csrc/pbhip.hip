@@ -39,6 +39,7 @@
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
 #define pbh_stream_stats PBH_FN(stream_stats)
+#define pbh_dedisperse_istft PBH_FN(dedisperse_istft)
 #define pbh_detect PBH_FN(detect)
 #define pbh_fft_c2c PBH_FN(fft_c2c)
 #define pbh_plan_profile PBH_FN(plan_profile)
@@ -2533,6 +2534,78 @@ int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nc
     io.out_pitch = out_pitch;
     auto steps = build_steps(p, (const cf*)p->stage_in, (cf*)out_dev, DetectTail(), io);
     return run_steps(steps, p->stream);
+}
+
+// coherent_dedispersion followed by contrib.istft in one call (transforms/dedispersion.py:125, then
+// pulsarbat/contrib/misc.py:58-93): `plan` is the dedispersion plan of the CHANNELISED block (nseg, nchan_out*nperseg,
+// inner), the output the (nout*nperseg, nchan_out, inner) time series of the synthesis filterbank, nout = stop - start.
+// Where the geometry allows (float32, nperseg = 2^m, a multi-pass plan, tiles that write at least 64-byte runs) the
+// dedispersion's last column pass leaves its cropped result series-major in the plan's staging buffer and k_istft_planar
+// reads that: no re-interleave pass, no reading the channelised result back.  Every other geometry runs the two steps.
+int PBH_FN(dedisperse_istft)(pbh_plan* p, const void* in_dev, int in_layout, int64_t in_pitch, int nperseg, int nchan_out,
+                             void* out_dev) {
+    if (!p || !in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
+    if (nperseg <= 0 || nchan_out <= 0 || (int64_t)nchan_out * nperseg != p->nchan)
+        return fail(PBH_ERR_INVALID, "pbh_dedisperse_istft: the plan must have nchan = nchan_out * nperseg channels");
+    if (in_layout != PBH_LAYOUT_SAMPLE_MAJOR && in_layout != PBH_LAYOUT_SERIES_MAJOR) return fail(PBH_ERR_INVALID, "bad layout");
+    if (in_layout == PBH_LAYOUT_SERIES_MAJOR && in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
+    const int64_t nout = p->stop - p->start;
+    HIPCHECK(hipSetDevice(p->device));
+    if (nout <= 0) return PBH_OK;
+    const int E = p->npol, M = nperseg;
+    const int64_t Sout = (int64_t)nchan_out * E;
+    const bool multipass = !(p->bsL || p->mixed || p->N1 == 1 || p->P > 1 || p->N1 > kTilePoints || p->N2 % (kTilePoints / p->N1) != 0 ||
+                             p->N >= (1LL << 31));
+    if (in_layout == PBH_LAYOUT_SERIES_MAJOR && !multipass)
+        return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan (nsample > one tile)");
+    IoLayout io;
+    io.in_layout = in_layout;
+    io.in_pitch = in_pitch;
+#ifndef PBH_F64
+    static const bool fuse_on = [] { const char* e = getenv("PBH_ISTFT_FUSE"); return e ? atoi(e) != 0 : true; }();
+    if (fuse_on && multipass && is_pow2(M) && M >= PBH_R && M * 16 <= kTilePoints) {
+        const int F = kTilePoints / M;
+        int SB = F / 16;
+        while (SB > 1 && (Sout % SB != 0 || SB > Sout)) SB >>= 1;
+        const int G = F / SB;
+        // the tile stores runs of SB series: below 64 bytes (or a part of the series only, narrower than that) the partial-line
+        // writes cost more than the pass the fusion saves
+        if (Sout / SB <= 16383 && (SB >= 8 || SB == Sout) && (int64_t)G * M * Sout * (int64_t)sizeof(cf) < (1LL << 31)) {
+            // series-major result of the dedispersion: row q' at q'*pitch, its first kept sample on a 128-byte line
+            const int64_t lead = p->start % 16, pitch = (nout + lead + 15) / 16 * 16;
+            PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, sizeof(cf) * (size_t)p->S * (size_t)pitch));
+            cf* mid = (cf*)p->stage_out + lead;
+            io.out_layout = PBH_LAYOUT_SERIES_MAJOR;
+            io.out_pitch = pitch;
+            auto steps = build_steps(p, (const cf*)in_dev, mid, DetectTail(), io);
+            PBHCHECK(run_steps(steps, p->stream));
+            IstftPlanarParams sp{(const cf*)mid, (cf*)out_dev, p->tw16k, pitch, nout, (int)Sout, E, SB, G};
+            const int64_t ngrp = (nout + G - 1) / G;
+            const size_t lds = (size_t)kTilePoints / 16 * 17 * sizeof(cf);   // staging rows padded to G + 1 slots, G >= 16 (one size: launch_tile_kernel sets the limit once)
+            int rc = PBH_OK;
+            for (int64_t y0 = 0; y0 < ngrp && rc == PBH_OK; y0 += 65535) {
+                const int64_t cnt = ngrp - y0 < 65535 ? ngrp - y0 : 65535;
+                IstftPlanarParams q = sp;
+                q.in = sp.in + y0 * G;
+                q.out = sp.out + y0 * G * (int64_t)M * Sout;
+                q.nseg = nout - y0 * G;
+                switch (M) {
+#define X(m) case m: rc = launch_tile_kernel(k_istft_planar<m, PBH_R>, q, Sout / SB, kTilePoints / PBH_R, p->stream, lds, (unsigned)cnt); break;
+                    X(32) X(64) X(128) X(256) X(512) X(1024)
+#undef X
+                    default: rc = fail(PBH_ERR_STATE, "k_istft_planar: unexpected segment length");
+                }
+            }
+            return rc;
+        }
+    }
+#endif
+    // unfused: dedisperse into the plan's staging buffer (reference layout), then the synthesis filterbank
+    PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, sizeof(cf) * (size_t)p->S * (size_t)nout));
+    auto steps = build_steps(p, (const cf*)in_dev, (cf*)p->stage_out, DetectTail(), io);
+    PBHCHECK(run_steps(steps, p->stream));
+    return PBH_FN(stft)(p->device, p->stream, 0, p->stage_out, out_dev, nout, M, nchan_out, E, 1, PBH_DEVICE, PBH_DEVICE);
 }
 
 static int launch_place(hipStream_t st, const cf* src, int64_t ipitch, cf* dst, int64_t opitch, int64_t nrow, int ncol) {

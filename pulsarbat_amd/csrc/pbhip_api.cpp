@@ -47,6 +47,7 @@
     int P##fft_c2c(int, void*, int, const void*, void*, int64_t, int64_t, int, int, int);                       \
     int P##stft(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                    \
     int P##stft_dedisperse(P##plan*, const void*, int, int, void*, int, int64_t);                               \
+    int P##dedisperse_istft(P##plan*, const void*, int, int64_t, int, int, void*);                              \
     int P##plan_profile(P##plan*, const void*, void*, int, float*, int*, const char**);                         \
     }
 PBH_DECLARE_IMPL(pbh32_)
@@ -238,6 +239,9 @@ int pbh_stft(int device, void* stream, int dtype, const void* in, void* out, int
 }
 int pbh_stft_dedisperse(pbh_plan* p, const void* in, int nperseg, int nchan_in, void* out, int ol, int64_t op) {
     FORWARD(p, pbh32_stft_dedisperse(P32(p), in, nperseg, nchan_in, out, ol, op), pbh64_stft_dedisperse(P64(p), in, nperseg, nchan_in, out, ol, op));
+}
+int pbh_dedisperse_istft(pbh_plan* p, const void* in, int il, int64_t ip, int nperseg, int nchan_out, void* out) {
+    FORWARD(p, pbh32_dedisperse_istft(P32(p), in, il, ip, nperseg, nchan_out, out), pbh64_dedisperse_istft(P64(p), in, il, ip, nperseg, nchan_out, out));
 }
 int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* ms, int* nk, const char** names) {
     FORWARD(p, pbh32_plan_profile(P32(p), in, out, iters, ms, nk, names), pbh64_plan_profile(P64(p), in, out, iters, ms, nk, names));

@@ -171,3 +171,47 @@ def test_stft_dedisperse_fused(shape, nperseg, dm):
     if shape[0] <= 1 << 20:
         yh = pb.contrib.stft_dedisperse(z, pb.DM(dm), nperseg=nperseg)
         assert isinstance(yh.data, np.ndarray) and np.allclose(np.asarray(yh), np.asarray(y), atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,nperseg,dm", [
+    ((1 << 21, 8, 2), 64, 30.0),     # 16 output series per tile: whole output lines
+    ((1 << 23, 2, 2), 256, 60.0),    # 4 output series: the tile takes all of them
+    ((1 << 22, 8, 2), 128, 80.0),    # 8 of the 16 series per tile: 64-byte runs
+    ((1 << 21, 8, 2), 512, 40.0),    # 2 of 16 series per tile: two steps in the one call
+    ((1 << 20, 3, 2), 32, 20.0),     # 6 output series: a subset size that divides them; the last tile of segments is short
+    ((1 << 22, 2), 128, 10.0),       # single-pol baseband signal
+    ((1 << 18, 4, 2), 2048, 5.0),    # beyond the fused kernel's segment lengths: two steps
+    ((1 << 16, 2, 2), 64, 1.0),      # channelised block of one tile: two steps
+])
+def test_dedisperse_istft_fused(shape, nperseg, dm):
+    """coherent_dedispersion followed by contrib.istft as one library call (pbh_dedisperse_istft) against the oracle's
+    composition of the two reference functions (dedispersion.py:118-133, misc.py:58-93) and against the product's own
+    two-call form.  The input is the channelised block the oracle's stft makes of a seeded time series."""
+    sr, fc = 8e6, 1.3e9
+    x = orc.synthetic_block(shape, 19)
+    ch = np.ascontiguousarray(orc.stft(x, nperseg)).astype(np.complex64)
+    kw = dict(sample_rate=sr / nperseg * u.Hz, center_freq=fc * u.Hz, freq_align="bottom",
+              start_time=pb.Time(56000.0, format="mjd"))
+    zc = (pb.DualPolarizationSignal(ch, pol_type="linear", **kw) if len(shape) == 3 else pb.BasebandSignal(ch, **kw))
+    zd = zc.to_device()
+    y = pb.contrib.dedisperse_istft(zd, pb.DM(dm), nperseg=nperseg)
+    mid, start, stop = orc.coherent_dedispersion(ch, dm, sr / nperseg, fc, freq_align="bottom")
+    want = orc.istft(mid, nperseg)
+    assert want.shape[0] > 0
+    assert isinstance(y.data, pb.DeviceArray) and type(y) is type(zc) and y.shape == want.shape
+    got = np.asarray(y).reshape(want.shape[0], -1)
+    ref = want.reshape(want.shape[0], -1)
+    err = np.linalg.norm(got - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    assert err.max() < 1e-5, f"per-series relative L2 {err.max():.2e}"
+    two = pb.contrib.istft(pb.coherent_dedispersion(zd, pb.DM(dm)), nperseg=nperseg)
+    assert_equal_radiosignals(y, two)
+    assert abs((y.start_time - zc.start_time).to_value(u.s) - start * nperseg / sr) < 1e-12
+    # a series-major channelised block (what stft_dedisperse(..., out_layout="series") style pipelines keep) gives the same
+    if len(shape) == 3 and zd.data.tensor.is_contiguous() and shape[0] // nperseg > 1 << 14:
+        zs = type(zd).like(zd, zd.data.to_series_major())
+        ys = pb.contrib.dedisperse_istft(zs, pb.DM(dm), nperseg=nperseg)
+        assert np.allclose(np.asarray(ys), np.asarray(y), atol=2e-6)   # (other layout passes in front: same values to rounding)
+    if shape[0] <= 1 << 20:   # host signals take the two-step route and agree
+        yh = pb.contrib.dedisperse_istft(zc, pb.DM(dm), nperseg=nperseg)
+        assert isinstance(yh.data, np.ndarray) and np.allclose(np.asarray(yh), np.asarray(y), atol=2e-6)

@@ -26,3 +26,15 @@ for nperseg in (32, 64, 128, 256, 512, 1024):
     c = timed(lambda: pb.contrib.stft_dedisperse(z, dm, nperseg=nperseg))
     print(f"nperseg {nperseg:5d}: stft {a:6.3f} ms | stft + dedispersion {b:6.3f} ms | fused {c:6.3f} ms "
           f"({tot / c / 1e6:5.1f} Gsamples/s)", flush=True)
+
+# the way back: coherent_dedispersion -> istft, fused (pbh_dedisperse_istft) against the two calls
+print("--- coherent_dedispersion -> istft")
+for nperseg in (32, 64, 128, 256, 512, 1024):
+    dm = pb.DM(56.77)
+    zc = pb.contrib.stft(z, nperseg=nperseg)
+    a = timed(lambda: pb.coherent_dedispersion(zc, dm))
+    b = timed(lambda: pb.contrib.istft(pb.coherent_dedispersion(zc, dm), nperseg=nperseg))
+    c = timed(lambda: pb.contrib.dedisperse_istft(zc, dm, nperseg=nperseg))
+    print(f"nperseg {nperseg:5d}: dedispersion {a:6.3f} ms | dedispersion + istft {b:6.3f} ms | fused {c:6.3f} ms "
+          f"({tot / c / 1e6:5.1f} Gsamples/s)", flush=True)
+    del zc
