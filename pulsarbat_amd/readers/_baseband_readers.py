@@ -8,6 +8,8 @@ lays the result out -- optionally series-major, the layout ``coherent_dedispersi
 Real-sampled data continue into ``real_to_complex`` on the device (:139-141).
 """
 
+import operator
+
 import numpy as np
 
 from .. import units as u
@@ -96,16 +98,33 @@ class BasebandReader(BaseReader):
             return np.ones(shape1, bool)
         return np.asarray(lsb, bool).reshape(shape1)
 
-    def _decode(self, offset, n, ncomp_real_factor=1):
-        """Device array (n * factor, axis1, axis2) of the stored samples from ``offset * factor``."""
+    def _decode(self, offset, n, ncomp_real_factor=1, channels=None):
+        """Device array (n * factor, axis1, axis2) of the stored samples from ``offset * factor``.  ``channels``
+        (a slice of axis1): only those channels are decoded, and where their bytes are a small contiguous part of every
+        block's payload (channel-major blocks: GUPPI raw) only those bytes are read from the file and cross PCIe."""
         raw = self._raw
         shape1, strides, elem0 = self._axes()
-        if n == 0:
-            return np.empty((0,) + tuple(shape1), np.complex64 if raw.complex_data else np.float32)
-        buf, first = raw.fetch(offset * ncomp_real_factor, n * ncomp_real_factor)
+        conj = self._conj_mask(shape1) if raw.complex_data else None
+        if channels is not None:
+            lo, hi, _ = channels.indices(shape1[0])
+            shape1 = (max(hi - lo, 0), shape1[1])
+            elem0 = elem0 + lo * strides[0]
+            conj = None if conj is None else conj[lo:hi]
+        if n == 0 or shape1[0] == 0:
+            return np.empty((n * ncomp_real_factor,) + tuple(shape1), np.complex64 if raw.complex_data else np.float32)
         lay = raw.layout()
         lay.update(elem0=elem0, stride_c=strides[0], stride_p=strides[1])
-        conj = self._conj_mask(shape1) if raw.complex_data else None
+        byte_range = None
+        if channels is not None and raw.gather is None:
+            # element indices a block's samples of these channels reach -> the payload bytes that hold them
+            ends = [elem0 + sum(st * e for st, e in zip((raw.stride_t, strides[0], strides[1]), c))
+                    for c in ((a, b, d) for a in (0, raw.blk_samples - 1) for b in (0, shape1[0] - 1) for d in (0, shape1[1] - 1))]
+            bits = lay["nbits"] * lay["ncomp"]
+            plo, phi = (min(ends) * bits // 8) // 16 * 16, -(-(max(ends) + 1) * bits // 8)
+            if 0 <= plo < phi <= raw.blk_bytes and (phi - plo) * 4 <= raw.blk_bytes * 3:
+                byte_range = (plo, phi)
+                lay.update(blk_stride=-(-(phi - plo) // 16) * 16, elem0=elem0 - plo * 8 // bits)
+        buf, first = raw.fetch(offset * ncomp_real_factor, n * ncomp_real_factor, byte_range=byte_range)
         return _hip.decode(buf, lay, first, n * ncomp_real_factor, shape1[0], shape1[1], conj=conj, scale=raw.scale,
                            series_major=self._series_major and raw.complex_data, device=self._device)
 
@@ -123,18 +142,43 @@ class BasebandReader(BaseReader):
     def _read_baseband(self, offset, n, /, **kwargs):
         """n samples from ``offset``: real data are read at twice the rate and converted
         (_baseband_readers.py:136-153)."""
+        channels = kwargs.get("channels")
         if self.real_baseband:
-            z = self._decode(offset, n, 2)
-            if n:
+            z = self._decode(offset, n, 2, channels=channels)
+            if n and z.shape[1]:
                 z = real_to_complex(z, axis=0)
-                mask = self._conj_mask(z.shape[1:])
+                mask = self._conj_mask(self._axes()[0])
+                if mask is not None and channels is not None:
+                    mask = mask[channels]
                 if mask is not None and mask.any():
                     z = type(z)(_conj_where(z.tensor, mask))
             else:
-                z = z.astype(np.complex64)
+                z = z.astype(np.complex64)[:n]
         else:
-            z = self._decode(offset, n)
+            z = self._decode(offset, n, channels=channels)
         return z
+
+    def read(self, offset, n, /, channels=None, **kwargs):
+        """``n`` samples from ``offset`` (reference readers/_base.py:298-333).  ``channels`` (a slice of the channel axis,
+        e.g. ``shard.channel_slice(nchan, world, rank)``): the signal of those channels only, equal to ``read(offset,
+        n)[:, channels]`` -- what a rank of a channel-sharded job needs -- without reading, uploading or decoding the
+        other channels where the file's blocks are channel-major (GUPPI raw)."""
+        if channels is None:
+            return super().read(offset, n, **kwargs)
+        if not isinstance(channels, slice) or channels.step not in (None, 1):
+            raise TypeError("channels must be a contiguous slice")
+        if self._squeeze and len(self._in_sample_shape) != len(self._raw.sample_shape):
+            raise ValueError("channels= needs the unsqueezed (channel, polarisation) sample axes")
+        full = super().read(offset, 0, **kwargs)   # bounds checks and the metadata of the whole band, no data
+        for ignored in ("use_dask", "chunks"):
+            kwargs.pop(ignored, None)
+        if operator.index(offset) + operator.index(n) > len(self):
+            from ._base import OutOfBoundsError
+            raise OutOfBoundsError("Cannot read beyond end of stream")
+        data = self._read_array(operator.index(offset), operator.index(n), channels=channels, **kwargs)
+        # frequency bookkeeping of the subset through the container's own channel slicing (core.py:479-498)
+        meta = full[:, channels] if hasattr(full, "channel_freqs") else full
+        return type(full).like(meta, data, start_time=self.time_at(operator.index(offset)))
 
     def _read_array(self, offset, n, /, **kwargs):
         return self._finish(self._read_baseband(offset, n, **kwargs))

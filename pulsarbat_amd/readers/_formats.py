@@ -50,23 +50,31 @@ class RawStream:
     files: list = field(default_factory=list, repr=False)
     gather: object = field(default=None, repr=False)          # optional per-block reader (VDIF frame sets)
     scale: float = 1.0           # factor applied to the unpacked integers (VDIF 4- / 8-bit normalisation)
+    bytes_fetched: int = field(default=0, repr=False, compare=False)   # of the last fetch()
 
     def layout(self):
         return dict(nbits=self.nbits, ncomp=2 if self.complex_data else 1, code=self.code, blk_samples=self.blk_samples,
                     blk_stride=self.blk_bytes, hdr_bytes=0, elem0=self.elem0, stride_t=self.stride_t,
                     stride_c=self.stride_1, stride_p=self.stride_2)
 
-    def fetch(self, offset, n):
+    def fetch(self, offset, n, byte_range=None):
         """Payload bytes of the blocks holding samples [offset, offset + n), one after the other, and the
-        index of sample ``offset`` counted from the start of the first of them."""
+        index of sample ``offset`` counted from the start of the first of them.  ``byte_range = (lo, hi)`` reads only
+        bytes [lo, hi) of every block's payload (a channel subset of a channel-major block), packed ``hi - lo`` rounded
+        up to 16 bytes apart.  ``bytes_fetched`` holds the number of bytes the last call read from the files."""
         if n <= 0:
             return np.empty(0, np.uint8), 0
         b0, b1 = offset // self.blk_samples, (offset + n - 1) // self.blk_samples
-        buf = np.empty((b1 - b0 + 1) * self.blk_bytes, np.uint8)
+        lo, hi = (0, self.blk_bytes) if byte_range is None or self.gather is not None else byte_range
+        if not 0 <= lo < hi <= self.blk_bytes:
+            raise ValueError("byte_range outside the payload")
+        width = hi - lo
+        pitch = self.blk_bytes if width == self.blk_bytes else -(-width // 16) * 16
+        buf = np.zeros((b1 - b0 + 1) * pitch, np.uint8) if pitch != width else np.empty((b1 - b0 + 1) * pitch, np.uint8)
         handles = {}
         try:
             for k, b in enumerate(range(b0, b1 + 1)):
-                dst = memoryview(buf)[k * self.blk_bytes:(k + 1) * self.blk_bytes]
+                dst = memoryview(buf)[k * pitch:k * pitch + width]
                 if self.gather is not None:
                     self.gather(self, b, dst, handles)
                     continue
@@ -74,12 +82,13 @@ class RawStream:
                 fh = handles.get(fi)
                 if fh is None:
                     fh = handles[fi] = open(self.files[fi], "rb", buffering=0)
-                fh.seek(pos)
-                if fh.readinto(dst) != self.blk_bytes:
+                fh.seek(pos + lo)
+                if fh.readinto(dst) != width:
                     raise EOFError(f"{self.files[fi]}: short read of block {b}")
         finally:
             for fh in handles.values():
                 fh.close()
+        self.bytes_fetched = (b1 - b0 + 1) * width
         return buf, offset - b0 * self.blk_samples
 
 

@@ -227,6 +227,37 @@ class TestDeviceDecode:
         if series_major:
             assert z.data.series_major_pitch() is not None
 
+    @pytest.mark.parametrize("series_major", [False, True])
+    def test_channel_selective_read(self, series_major):
+        """``read(offset, n, channels=slice)`` -- a rank's share of a channel-sharded job (shard.channel_slice) -- equals
+        ``read(offset, n)[:, channels]`` in values and frequency bookkeeping, and for channel-major blocks (GUPPI raw) only
+        that share of the file's payload bytes is read and uploaded (reference reader: whole blocks through
+        _baseband_readers.py:190-226, then the container's channel slicing core.py:479-498)."""
+        from pulsarbat_amd import shard
+        r = pbr.GUPPIRawReader(GUPPI, series_major=series_major)
+        nchan = r.sample_shape[0]
+        for world, rank in ((2, 0), (2, 1), (nchan, nchan - 1)):
+            sl = shard.channel_slice(nchan, world, rank)
+            full = r.read(1000, 20000)                     # many blocks, both files' boundaries
+            whole = r._raw.bytes_fetched
+            part = r.read(1000, 20000, channels=sl)
+            assert r._raw.bytes_fetched * world <= whole * 1.05, (r._raw.bytes_fetched, whole)
+            want = full[:, sl]
+            assert type(part) is type(full) and part.shape == want.shape and part.pol_type == want.pol_type
+            assert np.array_equal(np.asarray(part), np.asarray(want))
+            assert np.allclose(part.channel_freqs.to_value(u.Hz), want.channel_freqs.to_value(u.Hz))
+            assert u.isclose(part.sample_rate, want.sample_rate) and part.start_time.isclose(want.start_time)
+        assert len(r.read(5, 0, channels=slice(1, 2))) == 0
+        with pytest.raises(EOFError):
+            r.read(len(r) - 3, 4, channels=slice(0, 1))
+        with pytest.raises(TypeError):
+            r.read(0, 4, channels=[0, 1])
+        # a time-major payload (DADA): the channels' bytes are spread over every sample -- whole blocks travel, same values
+        d = pbr.DADAStokesReader(DATA / "stokes_ef.dada")
+        a, b = d.read(3, 13), d.read(3, 13, channels=slice(100, 612))
+        assert np.array_equal(np.asarray(b), np.asarray(a)[:, 100:612])
+        assert np.allclose(b.channel_freqs.to_value(u.Hz), a[:, 100:612].channel_freqs.to_value(u.Hz))
+
     def test_guppi_into_dedispersion(self):
         """The reader's series-major output is what coherent_dedispersion takes without layout passes."""
         r = pbr.GUPPIRawReader(GUPPI, series_major=True)
