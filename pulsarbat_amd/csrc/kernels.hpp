@@ -542,6 +542,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_row(RowParams p) {
                     if (cnt < R) { nx[cnt] = buf_load(rdn, voff, cnt * STEP); ++cnt; }
                 if constexpr (NST < 2) __syncthreads();
                 tnx = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)slot[0]);
+                if constexpr (NST < 2) __syncthreads();   // (and nobody is still reading the slot when thread 0 writes it again)
             } else if constexpr (SP && NST >= 2) {
                 // next tile requested stage by stage; outputs stored as the last stage produces them
                 constexpr int NBL = R / stage_radix(M, last_stage_ns(M, R), R);  // butterflies per thread in the last stage
@@ -708,8 +709,14 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i] = nx[i];
         if (last_pol) {
+            // The slot is written by thread 0 after the forward transform and read here by every wave.  With two or more
+            // stages the inverse transform's exchange barriers lie between the two; a 32-point row (7-smooth plans with five
+            // factors of two) is ONE stage without any exchange, and the waves raced: pairs handed out by the counter were
+            // transformed twice or not at all (found by tests/tools/fuzz_parity.py, seed 7: 1 372 000 samples x 9 channels).
+            if constexpr (stage_count(M, R) < 2) __syncthreads();
             u = unx;
             unx = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);
+            if constexpr (stage_count(M, R) < 2) __syncthreads();   // ... and everyone has read it before it is written again
         }
         pol = poln;
         rd = rdn;

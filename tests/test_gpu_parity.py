@@ -1174,3 +1174,21 @@ def test_7smooth_few_factors_user_chirp_and_shift():
     assert series_errors(np.asarray(pb.time_shift(z, -3.25)), orc.time_shift(x, -3.25)[0])[0] < RTOL_L2
     ft = 0.1371
     assert series_errors(np.asarray(pb.freq_shift(z, ft * 1e6 * u.Hz)), orc.freq_shift(x, ft))[0] < 2e-5
+
+
+@pytest.mark.parametrize("nchan,npol", [(9, 1), (7, 2)])
+def test_single_stage_rows_tile_handout(nchan, npol):
+    """7-smooth plan with 32-point rows (1 372 000 = 2^5 5^3 7^3): the phase row kernel's rows are ONE radix-32 stage with no
+    LDS exchange, so nothing ordered thread 0's write of the next-tile slot against the other waves' read of it -- every
+    (channel, row-group) pair beyond the first two per workgroup could be transformed twice or not at all, i.e. channels
+    >= 6 here were garbage.  Found by tests/tools/fuzz_parity.py (seed 7) in round 3; present since round 2."""
+    n, sr, fc, dm = 1372000, 25e6, 4e8, 1.0
+    shape = (n, nchan, npol) if npol > 1 else (n, nchan)
+    x = orc.synthetic_block(shape, 77)
+    z = make_signal(x, sr, fc)
+    y = pb.coherent_dedispersion(z.to_device(), pb.DM(dm))
+    want, start, stop = orc.coherent_dedispersion(x, dm, sr, fc)
+    got = np.asarray(y).reshape(stop - start, -1)
+    ref = want.reshape(stop - start, -1)
+    err = np.linalg.norm(got - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    assert err.max() < RTOL_L2, f"per-series relative L2 {err}"
