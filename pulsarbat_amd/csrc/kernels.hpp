@@ -731,7 +731,11 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
 // loaded and stored as 16 x 16 bytes per thread instead of 32 x 8.  Between the two transforms the points sit in the
 // natural distribution tau + 512 i, which is the order of the phase row.  (M = 2^14, float32.)
 // ABL (experiments): 1 = no transforms (memory traffic and the loop only)
-template <int R, int ABL = 0>
+// DS: deferred stores -- a tile's results are not stored in a burst behind its inverse transform (16 back-to-back 16-byte
+// stores per thread during which the wave issues nothing else) but stay in registers and leave one per tick of the NEXT tile's
+// forward transform, in the registers the next tile's samples vacated (k_colq's scheme; the loads already ride in the inverse
+// transform's ticks): memory traffic in both halves of an iteration, no burst.
+template <int R, int ABL = 0, bool DS = false>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
     constexpr int M = kTilePoints;
     static_assert(M == 16384 && R == 32, "k_rowp16: 2^14-point rows, 32 points per thread");
@@ -793,6 +797,12 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
     launder_all(wi, std::make_integer_sequence<int, NSI>{});
     float ph[R];
     unsigned fetched = 0;
+    cf out[R];                              // DS: the previous tile's results, waiting to be stored
+    rsrc_t wso = make_rsrc(obase, 0);       // ... and where they go (nothing yet: a zero-size descriptor drops the stores)
+    if constexpr (DS) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) out[i] = make_cf(0, 0);
+    }
 
     while (true) {
         launder_all(wf, std::make_integer_sequence<int, NSF>{});
@@ -817,7 +827,22 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
             }
         }
         // forward: 16 (pair-adjacent bases), 32, 32 -> natural distribution tau + 512 i
-        if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true, false, false, NoHook, 1, true, false>(v, lds, tau, 0, wf);
+        if constexpr (DS) {
+            int scnt = 0;
+            auto hkf = [&](auto st, auto q) {
+                if constexpr (std::is_same<decltype(q), tick_tag>::value) {   // the previous tile: one 16-byte store per tick
+                    __builtin_amdgcn_sched_barrier(0x38E);
+                    if (scnt < R / 2) { store_pair(wso, scnt, out[2 * scnt], out[2 * scnt + 1]); ++scnt; }
+                    __builtin_amdgcn_sched_barrier(0x38E);
+                }
+            };
+            if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true, false, false, decltype(hkf), 1, true, false>(v, lds, tau, 0, wf, hkf);
+#pragma unroll
+            for (int k = 0; k < R / 2; ++k)
+                if (scnt < R / 2) { store_pair(wso, scnt, out[2 * scnt], out[2 * scnt + 1]); ++scnt; }
+        } else {
+            if constexpr (ABL != 1) fft_tile<M, 1, R, -1, 1, true, false, false, NoHook, 1, true, false>(v, lds, tau, 0, wf);
+        }
         if (pol == 0) {   // the index of the pair after next: the atomic's round trip is waited for where the phase values are
                           // needed anyway (nothing else is in flight here), not at the top of the loop
             fetched = unx + G;
@@ -847,12 +872,19 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
         // inverse: 32, 32, 16 ending on pair-adjacent bases: v[q + 2 u] = X[2 tau + q + 1024 u]
         if constexpr (ABL != 1) fft_tile<M, 1, R, +1, 1, true, false, false, decltype(hk), 0, false, true>(v, lds, tau, 0, wi, hk);
         else __syncthreads();
+        if (!DS || !more) {   // (the last tile of a workgroup has no successor to hide its stores behind)
 #pragma unroll
-        for (int j = 0; j < R / 2; ++j) store_pair(ws, j, v[2 * j], v[2 * j + 1]);
+            for (int j = 0; j < R / 2; ++j) store_pair(ws, j, v[2 * j], v[2 * j + 1]);
+        }
 #pragma unroll
         for (int k = 0; k < R / 2; ++k)
             if (cnt < R / 2) { load_pair(rdn, cnt, nx[2 * cnt], nx[2 * cnt + 1]); ++cnt; }
         if (!more) break;
+        if constexpr (DS) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) out[i] = v[i];
+            wso = ws;
+        }
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i] = nx[i];
         if (last_pol) {

@@ -502,9 +502,12 @@ static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     int64_t tiles = (int64_t)prm.nchan * ((prm.N1 + FR - 1) / FR);
     if (tiles > row_grid()) tiles = row_grid();
     static const bool nofft = [] { const char* e = getenv("PBH_ROW16_NOFFT"); return e ? atoi(e) != 0 : false; }();
-    if (prm.phase16 && M == kTilePoints)
-        return nofft ? launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16)
-                     : launch_tile_kernel(k_rowp16<PBH_R, 0>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+    static const bool defer = [] { const char* e = getenv("PBH_ROW16_DEFER"); return e ? atoi(e) != 0 : false; }();   // deferred stores (A/B)
+    if (prm.phase16 && M == kTilePoints) {
+        if (nofft) return launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+        return defer ? launch_tile_kernel(k_rowp16<PBH_R, 0, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16)
+                     : launch_tile_kernel(k_rowp16<PBH_R, 0, false>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+    }
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_rowp<m, PBH_R>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         FOR_ROW_M(X)

@@ -60,7 +60,7 @@ def release_gathers():
     the group, e.g. before ``destroy_process_group``; the memory is otherwise held for re-use by later calls."""
     me = threading.get_ident()
     with _GATHERS_LOCK:
-        stale = [_GATHERS.pop(k) for k in sorted((k for k in _GATHERS if k[0] == me), key=repr)]
+        stale = [_GATHERS.pop(k) for k in [k for k in _GATHERS if k[0] == me]]   # insertion order: the same on every rank
     for g in stale:
         g.close()
 
