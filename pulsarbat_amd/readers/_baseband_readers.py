@@ -98,10 +98,11 @@ class BasebandReader(BaseReader):
             return np.ones(shape1, bool)
         return np.asarray(lsb, bool).reshape(shape1)
 
-    def _decode(self, offset, n, ncomp_real_factor=1, channels=None):
-        """Device array (n * factor, axis1, axis2) of the stored samples from ``offset * factor``.  ``channels``
-        (a slice of axis1): only those channels are decoded, and where their bytes are a small contiguous part of every
-        block's payload (channel-major blocks: GUPPI raw) only those bytes are read from the file and cross PCIe."""
+    def _subset_layout(self, channels=None):
+        """``(shape1, layout, byte_range, conj_mask)`` of a read / stream of ``channels`` (a slice of axis1; None = all): the
+        subset is expressed in the decode layout (``elem0``, channel count), and where its bytes are a small contiguous part
+        of every block's payload (channel-major blocks: GUPPI raw) ``byte_range`` is that part and the layout describes the
+        PACKED blocks ``RawStream.fetch(byte_range=...)`` returns -- only those bytes are read from the file and cross PCIe."""
         raw = self._raw
         shape1, strides, elem0 = self._axes()
         conj = self._conj_mask(shape1) if raw.complex_data else None
@@ -110,12 +111,10 @@ class BasebandReader(BaseReader):
             shape1 = (max(hi - lo, 0), shape1[1])
             elem0 = elem0 + lo * strides[0]
             conj = None if conj is None else conj[lo:hi]
-        if n == 0 or shape1[0] == 0:
-            return np.empty((n * ncomp_real_factor,) + tuple(shape1), np.complex64 if raw.complex_data else np.float32)
         lay = raw.layout()
         lay.update(elem0=elem0, stride_c=strides[0], stride_p=strides[1])
         byte_range = None
-        if channels is not None and raw.gather is None:
+        if channels is not None and raw.gather is None and shape1[0] > 0:
             # element indices a block's samples of these channels reach -> the payload bytes that hold them
             ends = [elem0 + sum(st * e for st, e in zip((raw.stride_t, strides[0], strides[1]), c))
                     for c in ((a, b, d) for a in (0, raw.blk_samples - 1) for b in (0, shape1[0] - 1) for d in (0, shape1[1] - 1))]
@@ -124,6 +123,15 @@ class BasebandReader(BaseReader):
             if 0 <= plo < phi <= raw.blk_bytes and (phi - plo) * 4 <= raw.blk_bytes * 3:
                 byte_range = (plo, phi)
                 lay.update(blk_stride=-(-(phi - plo) // 16) * 16, elem0=elem0 - plo * 8 // bits)
+        return shape1, lay, byte_range, conj
+
+    def _decode(self, offset, n, ncomp_real_factor=1, channels=None):
+        """Device array (n * factor, axis1, axis2) of the stored samples from ``offset * factor`` (``channels``: a slice of
+        axis1, see ``_subset_layout``)."""
+        raw = self._raw
+        shape1, lay, byte_range, conj = self._subset_layout(channels)
+        if n == 0 or shape1[0] == 0:
+            return np.empty((n * ncomp_real_factor,) + tuple(shape1), np.complex64 if raw.complex_data else np.float32)
         buf, first = raw.fetch(offset * ncomp_real_factor, n * ncomp_real_factor, byte_range=byte_range)
         return _hip.decode(buf, lay, first, n * ncomp_real_factor, shape1[0], shape1[1], conj=conj, scale=raw.scale,
                            series_major=self._series_major and raw.complex_data, device=self._device)

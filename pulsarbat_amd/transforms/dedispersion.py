@@ -290,7 +290,7 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
 
 
-def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto", offset=0, n=None):
+def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto", offset=0, n=None, channels=None):
     """Overlap-save dedispersion of a long host-resident signal in chunks of ``chunk`` samples.
 
     Equals ``pb.concatenate([coherent_dedispersion(z[k*hop : k*hop + chunk], DM, ref_freq=ref)
@@ -302,11 +302,16 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     ``z`` may also be a ``pulsarbat_amd.readers.BasebandReader`` of complex voltage data (``offset`` / ``n`` select
     the samples): then the file's payload bytes are what crosses PCIe and every chunk is unpacked on the
     device in front of its transforms (``pbh_dedisperse_stream_raw``) -- the same result as streaming
-    ``reader.read(offset, n)``, at a quarter of the upload for 8-bit samples.
+    ``reader.read(offset, n)``, at a quarter of the upload for 8-bit samples.  With a reader, ``channels`` (a slice, e.g.
+    ``shard.channel_slice(nchan, world, rank)``) streams a rank's share of a channel-sharded job: the result equals the
+    full stream's ``[:, channels]`` -- crop and reference frequency are the FULL band's (dedispersion.py:118-131), the
+    chirp the subset's -- and for channel-major files only that share of the payload is read and uploaded.
     """
     from ..readers import BasebandReader
     if isinstance(z, BasebandReader):
-        return _stream_from_reader(z, DM, chunk, ref_freq, variant, offset, n)
+        return _stream_from_reader(z, DM, chunk, ref_freq, variant, offset, n, channels)
+    if channels is not None:
+        raise TypeError("channels= applies to streaming from a reader; slice a signal with z[:, channels]")
     if not isinstance(z, BasebandSignal):
         raise TypeError("Signal must be a BasebandSignal object.")
     if isinstance(z.data, DeviceArray):
@@ -322,7 +327,7 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     return type(z).like(z, y, **_advance(z, start)), ms
 
 
-def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n):
+def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n, channels=None):
     if not issubclass(reader._signal_type, BasebandSignal) or reader.intensity or not reader.complex_data:
         raise TypeError("streaming from a reader needs complex voltage data in a BasebandSignal type")
     n = len(reader) - offset if n is None else n
@@ -334,23 +339,30 @@ def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n):
                                **reader._signal_kwargs)
     if ref_freq is None:
         ref_freq = head.center_freq
-    start, stop = _crop_bounds(head, DM, ref_freq)
+    start, stop = _crop_bounds(head, DM, ref_freq)          # the FULL band's, whatever the channel subset
+    if channels is not None:
+        if not isinstance(channels, slice) or channels.step not in (None, 1):
+            raise TypeError("channels must be a contiguous slice")
+        if len(reader.sample_shape) != len(reader._raw.sample_shape):
+            raise ValueError("channels= needs the unsqueezed (channel, polarisation) sample axes")
+        head = head[:, channels]                            # the container's own channel bookkeeping (core.py:479-498)
+        if head.shape[1] == 0:
+            raise ValueError("channels selects no channel")
     plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
-    shape1, strides, elem0 = reader._axes()
+    shape1, lay, byte_range, mask = reader._subset_layout(channels)
     if tuple(shape1) != (plan.nchan, plan.npol):
         # unit axes dropped by squeezing: the remaining one is the channel axis
         keep = [i for i in (0, 1) if shape1[i] != 1]
         if len(keep) != 1 or shape1[keep[0]] != plan.nchan or plan.npol != 1:
             raise ValueError(f"reader samples {tuple(shape1)} do not map onto ({plan.nchan}, {plan.npol}) series")
-        strides = (strides[keep[0]], 0)
-    buf, first = reader._raw.fetch(offset, n)
-    lay = reader._raw.layout()
-    lay.update(elem0=elem0, stride_c=strides[0], stride_p=strides[1])
-    mask = reader._conj_mask(shape1)
+        if keep[0] == 1:
+            lay.update(stride_c=lay["stride_p"])
+        lay.update(stride_p=0)
+    buf, first = reader._raw.fetch(offset, n, byte_range=byte_range)
     if mask is not None:
         mask = np.asarray(mask).reshape(plan.nchan, plan.npol)
     y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask, scale=reader._raw.scale)
-    y = y.reshape((len(y),) + reader.sample_shape)
+    y = y.reshape((len(y),) + tuple(head.shape[1:]))
     return type(head).like(head, y, **_advance(head, start)), ms
 
 

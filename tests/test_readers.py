@@ -354,6 +354,24 @@ class TestRawStream:
         assert y2.shape == y3.shape and y2.start_time.isclose(y3.start_time)
         assert np.linalg.norm(np.asarray(y2) - np.asarray(y3)) / np.linalg.norm(np.asarray(y3)) < 2e-6
 
+    def test_sharded_reader_stream(self):
+        """A rank's share of a channel-sharded stream from a file: ``channels=`` gives the full stream's ``[:, channels]``
+        (full-band crop and reference frequency) while reading and uploading only that share of a channel-major file."""
+        from pulsarbat_amd import shard
+        r = pbr.GUPPIRawReader(GUPPI)
+        full, _ = pb.coherent_dedispersion_stream(r, pb.DM(0.5), chunk=1 << 13)
+        whole = r._raw.bytes_fetched
+        for rank in range(2):
+            sl = shard.channel_slice(r.sample_shape[0], 2, rank)
+            part, _ = pb.coherent_dedispersion_stream(r, pb.DM(0.5), chunk=1 << 13, channels=sl)
+            assert r._raw.bytes_fetched * 2 <= whole * 1.05
+            want = full[:, sl]
+            assert type(part) is type(full) and part.shape == want.shape and part.start_time.isclose(want.start_time)
+            assert np.allclose(part.channel_freqs.to_value(u.Hz), want.channel_freqs.to_value(u.Hz))
+            assert np.linalg.norm(np.asarray(part) - np.asarray(want)) / np.linalg.norm(np.asarray(want)) < 2e-6
+        with pytest.raises(TypeError):
+            pb.coherent_dedispersion_stream(full, pb.DM(0.5), chunk=1 << 13, channels=slice(0, 1))
+
     def test_synthetic_blocks(self, monkeypatch):
         """Headered blocks, offset-binary samples, a conjugation mask and a scale: equals the stream over
         the numpy-decoded array."""
