@@ -1250,6 +1250,7 @@ struct StftPlanarParams {
     int S, E;          // series of the input (nchan*E), inner elements per channel
     int SB, G;         // series per tile, segments per tile (SB*G = tile/M)
     real scale;        // 1/M
+    int nsub = 1;      // sibling tiles (the other series subsets of the same segments) a workgroup does one after the other
 };
 
 template <int M, int R>
@@ -1264,12 +1265,19 @@ __global__ __launch_bounds__(kTilePoints / R) void k_stft_planar(StftPlanarParam
     const int tid = threadIdx.x;
     const int f = tid % F, tau = tid / F;
     const int j = f % p.SB, sl = f / p.SB;
-    const int q0 = blockIdx.x * p.SB;
     const int64_t g0 = (int64_t)blockIdx.y * p.G;
 
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
 
+    // Sibling tiles read the SAME 128-byte lines of the input (SB of its S series each).  As separate workgroups they land on
+    // different XCDs (consecutive workgroups are dealt round the eight of them) and every L2 fetches the lines again: with
+    // SB < 8 the input crossed the fabric S/SB times and the fused call lost to two steps.  One workgroup doing the siblings
+    // one after the other re-reads the lines out of its own L2 a few microseconds later.
+    for (int sub = 0; sub < p.nsub; ++sub) {
+    launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
+    const int q0 = (blockIdx.x * p.nsub + sub) * p.SB;
+    if (sub) __syncthreads();   // the previous sibling's staging reads are done
     const rsrc_t ri = make_rsrc(p.in + (g0 * M) * (int64_t)p.S + q0, (uint32_t)(((int64_t)p.G * M * p.S - q0) * (int64_t)sizeof(cf)));
     const int voff = (int)(((int64_t)sl * M * p.S + (int64_t)tau * p.S + j) * (int64_t)sizeof(cf));
     const int step = MR * p.S * (int)sizeof(cf);
@@ -1298,6 +1306,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_stft_planar(StftPlanarParam
             base[(int64_t)(k ^ (M / 2)) * kstep] = make_cf(x.x * p.scale, x.y * p.scale);
         }
     }
+    }
 }
 
 // ---- contrib.istft fed series-major: the synthesis filterbank behind coherent_dedispersion -------------------------
@@ -1317,6 +1326,8 @@ struct IstftPlanarParams {
     int64_t nseg;      // segments that exist from this launch's first one on (the last tile may be short)
     int S, E;          // series of the output (nchan_out*E), inner elements per channel
     int SB, G;         // series per tile, segments per tile (SB*G = tile/M)
+    int nsub = 1;      // sibling tiles a workgroup does one after the other (k_stft_planar): their partial lines of the output
+                       // meet in one L2 within microseconds and leave it as whole lines
 };
 
 template <int M, int R>
@@ -1331,12 +1342,15 @@ __global__ __launch_bounds__(kTilePoints / R) void k_istft_planar(IstftPlanarPar
     const int tid = threadIdx.x;
     const int f = tid % F, tau = tid / F;
     const int j = f % p.SB, sl = f / p.SB;
-    const int q0 = blockIdx.x * p.SB;
     const int64_t g0 = (int64_t)blockIdx.y * p.G;
     const int GP = p.G + 1;                  // padded row of the staging image
 
     cf w[tw_seeds_or1(M, R)];
     load_tw_seeds<M, 1, R>(w, tau, p.tw16k);
+    for (int sub = 0; sub < p.nsub; ++sub) {
+    launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
+    const int q0 = (blockIdx.x * p.nsub + sub) * p.SB;
+    if (sub) __syncthreads();   // the previous sibling's transform is done with the tile
     {
         // thread tid, round i: bin k = k0 + i*NT/F of series jj, segment ss (ss fastest across lanes)
         const int ss = tid % p.G, rest = tid / p.G;
@@ -1368,6 +1382,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_istft_planar(IstftPlanarPar
     const int step = MR * p.S * (int)sizeof(cf);
 #pragma unroll
     for (int i = 0; i < R; ++i) buf_store(ro, voff, i * step, v[i]);
+    }
 }
 
 // ---- contrib.stft / istft with one segment per tile (nperseg = 2^tile) and an even number of inner elements ----

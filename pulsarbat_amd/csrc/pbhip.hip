@@ -2466,6 +2466,16 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
     return PBH_OK;
 }
 
+// PBH_STFT_SIBLINGS=1 (experiment, round 3): fused tiles that take fewer than 8 of many series -- nperseg 256 / 512 with 16
+// series -- run with one workgroup doing all the sibling subsets of its segments (so that the shared 128-byte lines meet in
+// one L2) instead of falling back to two steps.  It does not pay: 5.10 vs 4.90 ms (256) and 6.67 vs 4.95 ms (512) forward,
+// 5.42 vs 4.86 and 6.53 vs 4.68 inverse (profiles/r03_stft_dedisp_fused.txt) -- the cost of 32- and 16-byte pieces is the
+// address work per byte in the CU's texture path, not a re-fetch across XCDs.  Default: two steps for those geometries.
+static bool stft_sibling_loop() {
+    static const bool on = [] { const char* e = getenv("PBH_STFT_SIBLINGS"); return e ? atoi(e) != 0 : false; }();
+    return on;
+}
+
 // contrib.stft followed by coherent_dedispersion in one call (pulsarbat/contrib/misc.py:41-55, then
 // transforms/dedispersion.py:125): `plan` is the dedispersion plan of the CHANNELISED block, (nseg, nchan_in*nperseg,
 // inner); the input is the (nseg*nperseg, nchan_in, inner) block the channeliser would read.  Where the geometry
@@ -2501,8 +2511,16 @@ int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nc
         const int G = F / SB;
         // (a tile that takes fewer than 8 of many series reads 32-byte or smaller pieces of the input's lines: slower
         //  than the two steps it would replace -- nperseg 256: 5.6 vs 5.2 ms, 512: 6.6 vs 5.0 for 2^24 x 8 x 2)
-        if (nseg % G == 0 && Sin / SB <= 16383 && (SB >= 8 || SB == Sin)) {
+        // tiles that take fewer than 8 of many series (32-byte or smaller pieces of the input's lines): one workgroup does all
+        // the sibling subsets of its segments, so that the lines are fetched into ONE L2 once
+        int nsub = 1;
+        if (SB < 8 && SB != Sin) {
+            nsub = (int)(Sin / SB);
+            while (nsub > 16 || (Sin / SB) % nsub != 0) --nsub;
+        }
+        if (nseg % G == 0 && Sin / SB <= 16383 && (SB >= 8 || SB == Sin || (stft_sibling_loop() && SB >= 2 && nsub * SB * (int)sizeof(cf) >= 64))) {
             StftPlanarParams sp{(const cf*)in_dev, p->work, p->tw16k, p->N, (int)Sin, E, SB, G, (real)(1.0 / (double)M)};
+            sp.nsub = nsub;
             const int64_t ngrp = nseg / G;
             int rc = PBH_OK;
             for (int64_t y0 = 0; y0 < ngrp && rc == PBH_OK; y0 += 65535) {
@@ -2511,7 +2529,7 @@ int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nc
                 q.in = sp.in + y0 * G * (int64_t)M * Sin;
                 q.out = sp.out + y0 * G;
                 switch (M) {
-#define X(m) case m: rc = launch_tile_kernel(k_stft_planar<m, PBH_R>, q, Sin / SB, kTilePoints / PBH_R, p->stream, lds_tile_bytes<false>(), (unsigned)cnt); break;
+#define X(m) case m: rc = launch_tile_kernel(k_stft_planar<m, PBH_R>, q, Sin / SB / nsub, kTilePoints / PBH_R, p->stream, lds_tile_bytes<false>(), (unsigned)cnt); break;
                     X(32) X(64) X(128) X(256) X(512) X(1024)
 #undef X
                     default: rc = fail(PBH_ERR_STATE, "k_stft_planar: unexpected segment length");
@@ -2574,7 +2592,13 @@ int PBH_FN(dedisperse_istft)(pbh_plan* p, const void* in_dev, int in_layout, int
         const int G = F / SB;
         // the tile stores runs of SB series: below 64 bytes (or a part of the series only, narrower than that) the partial-line
         // writes cost more than the pass the fusion saves
-        if (Sout / SB <= 16383 && (SB >= 8 || SB == Sout) && (int64_t)G * M * Sout * (int64_t)sizeof(cf) < (1LL << 31)) {
+        int nsub = 1;   // as in pbh_stft_dedisperse: narrow tiles are done sibling after sibling by one workgroup
+        if (SB < 8 && SB != Sout) {
+            nsub = (int)(Sout / SB);
+            while (nsub > 16 || (Sout / SB) % nsub != 0) --nsub;
+        }
+        if (Sout / SB <= 16383 && (SB >= 8 || SB == Sout || (stft_sibling_loop() && SB >= 2 && nsub * SB * (int)sizeof(cf) >= 64)) &&
+            (int64_t)G * M * Sout * (int64_t)sizeof(cf) < (1LL << 31)) {
             // series-major result of the dedispersion: row q' at q'*pitch, its first kept sample on a 128-byte line
             const int64_t lead = p->start % 16, pitch = (nout + lead + 15) / 16 * 16;
             PBHCHECK(ensure_stage(p, &p->stage_out, &p->stage_out_bytes, sizeof(cf) * (size_t)p->S * (size_t)pitch));
@@ -2584,6 +2608,7 @@ int PBH_FN(dedisperse_istft)(pbh_plan* p, const void* in_dev, int in_layout, int
             auto steps = build_steps(p, (const cf*)in_dev, mid, DetectTail(), io);
             PBHCHECK(run_steps(steps, p->stream));
             IstftPlanarParams sp{(const cf*)mid, (cf*)out_dev, p->tw16k, pitch, nout, (int)Sout, E, SB, G};
+            sp.nsub = nsub;
             const int64_t ngrp = (nout + G - 1) / G;
             const size_t lds = (size_t)kTilePoints / 16 * 17 * sizeof(cf);   // staging rows padded to G + 1 slots, G >= 16 (one size: launch_tile_kernel sets the limit once)
             int rc = PBH_OK;
@@ -2594,7 +2619,7 @@ int PBH_FN(dedisperse_istft)(pbh_plan* p, const void* in_dev, int in_layout, int
                 q.out = sp.out + y0 * G * (int64_t)M * Sout;
                 q.nseg = nout - y0 * G;
                 switch (M) {
-#define X(m) case m: rc = launch_tile_kernel(k_istft_planar<m, PBH_R>, q, Sout / SB, kTilePoints / PBH_R, p->stream, lds, (unsigned)cnt); break;
+#define X(m) case m: rc = launch_tile_kernel(k_istft_planar<m, PBH_R>, q, Sout / SB / nsub, kTilePoints / PBH_R, p->stream, lds, (unsigned)cnt); break;
                     X(32) X(64) X(128) X(256) X(512) X(1024)
 #undef X
                     default: rc = fail(PBH_ERR_STATE, "k_istft_planar: unexpected segment length");
