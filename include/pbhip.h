@@ -353,6 +353,14 @@ int pbh_plan_profile(pbh_plan* plan, const void* in_dev, void* out_dev, int iter
                      float* ms_per_kernel /* [PBH_MAX_KERNELS] */, int* nkernel,
                      const char** names /* [PBH_MAX_KERNELS], static strings */);
 
+/* utils.real_to_complex (pulsarbat/utils.py:15-65) of device-resident float32 data: in (nreal, nseries) float32 C order,
+ * out (nreal/2, nseries) complex64 C order.  Runs as a HALF-LENGTH complex transform (the real series, time fastest, is
+ * the complex series x[2m] + i x[2m+1]; one mirror pass turns its spectrum into the decimated analytic signal's): two
+ * transforms of nreal/2 points instead of two of nreal points on a complex copy.  nreal/2 must be a power of two in
+ * [2^15, 2^24]; other sizes return PBH_ERR_UNSUPPORTED (the host then takes the full-length route through a filter plan,
+ * pbh_chirp_special mode 2 + pbh_decimate2).  Asynchronous on hip_stream.                                             */
+int pbh_real_to_complex(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nreal, int nseries);
+
 /* Device-to-device streaming copy of `bytes` (float4 per lane): the achievable-HBM reference number. */
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean);
 

@@ -118,6 +118,7 @@ SIGNATURES = {
     "pbh_stft_dedisperse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64]),
     "pbh_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "pbh_real_to_complex": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pbh_copy_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
 }
 
@@ -685,6 +686,23 @@ def zero_edges(x_dev, shift):
     _check(lib().pbh_zero_edges(x_dev.device_index, _stream_ptr(x_dev.device_index), _dtype_code(x_dev.dtype),
                                 C.c_void_p(x_dev.data_ptr()), int(n), s, a.ctypes.data_as(C.POINTER(C.c_double))))
     return x_dev
+
+
+def real_to_complex_half(x_dev):
+    """``utils.real_to_complex`` of a C-contiguous device (n, s) float32 array as a half-length complex transform
+    (``pbh_real_to_complex``); returns the (n/2, s) complex64 DeviceArray, or None when the geometry is not covered."""
+    from .device import DeviceArray
+    n, s = int(x_dev.shape[0]), int(np.prod(x_dev.shape[1:]))
+    m = n // 2
+    if x_dev.dtype != np.float32 or n % 2 or m & (m - 1) or not (1 << 15) <= m <= (1 << 24) or s > 65535 or os.environ.get("PBH_R2C_HALF", "1") == "0":
+        return None
+    out = DeviceArray.empty((m,) + tuple(x_dev.shape[1:]), np.complex64, device=x_dev.device_index)
+    rc = lib().pbh_real_to_complex(x_dev.device_index, _stream_ptr(x_dev.device_index), C.c_void_p(x_dev.data_ptr()),
+                                   C.c_void_p(out.data_ptr()), n, s)
+    if rc == -2:      # PBH_ERR_UNSUPPORTED: the full-length route
+        return None
+    _check(rc)
+    return out
 
 
 def decimate2(y_dev):

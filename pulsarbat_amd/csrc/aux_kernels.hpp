@@ -1310,6 +1310,62 @@ __global__ __launch_bounds__(256) void k_pol_basis(const cf* __restrict__ in, cf
 }
 
 #ifndef PBH_F64
+// ---- utils.real_to_complex as a HALF-LENGTH complex transform (pulsarbat/utils.py:38-65) -----------------------------
+// A real series x of N samples, stored time fastest, IS the complex series p[m] = x[2m] + i x[2m+1] of M = N/2 samples.
+// With P = FFT_M(p): X[k] = E[k] + W_N^k O[k], E = (P[k] + conj P[M-k])/2, O = -i (P[k] - conj P[M-k])/2 is the real
+// transform's positive half, and the reference's recipe -- Hilbert weights, mixer exp(-i pi n/2), every second sample --
+// collapses to z = IFFT_M(C) with C[k'] = X[(k' + M/2) mod M] and C[M/2] = Re P[0]: two transforms of HALF the length
+// instead of two of the full length on a complex copy.
+
+// (N, S) float32 sample-major -> planar [s][n] (the planar complex work buffer seen as floats), 64 samples x min(S, 64) series
+__global__ __launch_bounds__(256) void k_real_planar(const float* __restrict__ in, float* __restrict__ out, int64_t N, int S,
+                                                     int64_t plane) {
+    __shared__ float t[64][65];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 64;
+    const int sw = S - s0 < 64 ? S - s0 : 64;             // series in this tile
+    const int nt = N - n0 < 64 ? (int)(N - n0) : 64;      // samples in this tile
+    if (sw == S) {   // all series: the tile is one contiguous run of nt * S floats
+        const float* src = in + n0 * S;
+        for (int i = threadIdx.x; i < nt * S; i += 256) t[i / S][i % S] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < nt * sw; i += 256) t[i / sw][i % sw] = in[(n0 + i / sw) * S + s0 + i % sw];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < sw * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;                 // series r, sample c: samples fastest across lanes
+        if (c < nt) out[(int64_t)(s0 + r) * plane + n0 + c] = t[c][r];
+    }
+}
+
+// P, C: plan order (series s at s*M, bin k = k1 + N1 k2 at k1*N2 + k2), out of place.  One thread per bin of the row pair
+// (k1, N1 - k1): it reads P[k] and P[M - k] once and writes both bins' outputs.
+__global__ __launch_bounds__(256) void k_r2c_mirror(const cf* __restrict__ P, cf* __restrict__ C, int N1, int N2, real scale) {
+    const int chunks = N2 / 256;
+    const int pr = blockIdx.x / chunks, k2 = (blockIdx.x - pr * chunks) * 256 + threadIdx.x;
+    const int A = pr, B = (N1 - pr) % N1;
+    const int64_t base = (int64_t)blockIdx.y * N1 * N2;
+    const int k2m = A == 0 ? (N2 - k2) % N2 : N2 - 1 - k2;          // M - k sits in row B at this column
+    const cf a = P[base + (int64_t)A * N2 + k2], b = P[base + (int64_t)B * N2 + k2m];
+    const int64_t k = A + (int64_t)N1 * k2;
+    // W_N^k = exp(-2 pi i k / N), N = 2 N1 N2: k / N is exact in float32 (k < 2^24, N a power of two)
+    const float rev = (float)k / (2.0f * (float)N1 * (float)N2);
+    const cf w = make_cf(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
+    const int h = N2 / 2;
+    {
+        const cf E = make_cf((a.x + b.x) * RC(0.5), (a.y - b.y) * RC(0.5));
+        const cf O = make_cf((a.y + b.y) * RC(0.5), -(a.x - b.x) * RC(0.5));          // -i (a - conj b) / 2
+        const cf X = k == 0 ? make_cf(a.x, 0) : cadd(E, cmul(w, O));                   // C[M/2] = Re P[0]
+        C[base + (int64_t)A * N2 + (k2 ^ h)] = make_cf(X.x * scale, X.y * scale);
+    }
+    if (A != B) {   // the mirror bin M - k: the roles of a and b swap, W^(M-k) = -conj W^k
+        const cf E = make_cf((b.x + a.x) * RC(0.5), (b.y - a.y) * RC(0.5));
+        const cf O = make_cf((b.y + a.y) * RC(0.5), -(b.x - a.x) * RC(0.5));
+        const cf X = cadd(E, cmul(make_cf(-w.x, w.y), O));
+        C[base + (int64_t)B * N2 + (k2m ^ h)] = make_cf(X.x * scale, X.y * scale);
+    }
+}
+
 // ---- streaming copy: the achievable-HBM yardstick --------------------------------------------------------
 // One contiguous 16-KiB chunk per workgroup, four 16-byte loads in flight per lane: the fastest plain copy on MI355X
 // (tools/micro/membench.hip, profiles/r01_membench.txt: 5.93 TB/s; a grid-stride loop reaches 4.7-5.0, hipMemcpyDtoD 5.3).

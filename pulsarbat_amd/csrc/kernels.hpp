@@ -898,8 +898,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
 }
 #endif  // !PBH_F64
 
-// ---- forward-only row FFT, in place (builds the Bluestein kernel's spectrum in plan order) -------------------
-template <int M, int R>
+// ---- stand-alone row FFT, in place (the Bluestein kernel's spectrum in plan order; DIR = +1: the unscaled inverse) ------
+template <int M, int R, int DIR = -1>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowfft(cf* data, const cf* tw16k, int64_t nrows) {
     constexpr int FR = kTilePoints / M, MR = M / R, STEP = MR * (int)sizeof(cf);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowfft(cf* data, const cf* 
     cf v[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) v[i] = buf_load(rd, voff, i * STEP);
-    fft_tile<M, 1, R, -1, 1, true>(v, lds, tau, f * M, w);
+    fft_tile<M, 1, R, DIR, 1, true>(v, lds, tau, f * M, w);
 #pragma unroll
     for (int i = 0; i < R; ++i) buf_store(rd, voff, i * STEP, v[i]);
 }

@@ -40,6 +40,7 @@
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
 #define pbh_stream_stats PBH_FN(stream_stats)
 #define pbh_dedisperse_istft PBH_FN(dedisperse_istft)
+#define pbh_real_to_complex PBH_FN(real_to_complex)
 #define pbh_detect PBH_FN(detect)
 #define pbh_fft_c2c PBH_FN(fft_c2c)
 #define pbh_plan_profile PBH_FN(plan_profile)
@@ -1638,14 +1639,13 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows 
     return PBH_OK;
 }
 
-static int launch_rowfft(int M, cf* data, const cf* tw, int64_t nrows, hipStream_t st) {
+static int launch_rowfft(int M, cf* data, const cf* tw, int64_t nrows, hipStream_t st, bool inverse = false) {
     const int FR = kTilePoints / M;
     const int64_t tiles = (nrows + FR - 1) / FR;
-    struct Args { cf* data; const cf* tw; int64_t nrows; };
     switch (M) {
 #define X(m)                                                                                               \
     case m: {                                                                                              \
-        auto kern = k_rowfft<m, PBH_R>;                                                                    \
+        auto kern = inverse ? k_rowfft<m, PBH_R, +1> : k_rowfft<m, PBH_R, -1>;                             \
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                      lds_tile_bytes<true>()));                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kTilePoints / PBH_R), lds_tile_bytes<true>(), st, \
@@ -3090,6 +3090,61 @@ static int fft_c2c_native(int device, hipStream_t st, const cf* din, cf* dout, i
     HIPCHECK(hipGetLastError());
     return PBH_OK;
 }
+
+#ifndef PBH_F64
+// utils.real_to_complex (pulsarbat/utils.py:15-65) of device-resident float32 data as a half-length complex transform
+// (aux_kernels.hpp, "utils.real_to_complex as a HALF-LENGTH complex transform"): in (nreal, nseries) float32 sample-major,
+// out (nreal/2, nseries) complex64 sample-major.  Geometries: nreal/2 a power of two the native column / row passes
+// transform unsplit (2^15 .. 2^24); anything else returns PBH_ERR_UNSUPPORTED and the caller takes the full-length route.
+int pbh_real_to_complex(int device, void* hip_stream, const void* in_dev, void* out_dev, int64_t nreal, int nseries) {
+    if (!in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
+    if (nreal <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
+    const int64_t M = nreal / 2;
+    if (nreal % 2 || !is_pow2(M) || !native_fft_ok(M, nseries) || nseries > 65535)
+        return fail(PBH_ERR_UNSUPPORTED, "half-length real_to_complex: nreal / 2 must be a power of two beyond one tile");
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    pbh_plan* p = nullptr;
+    PBHCHECK(native_fft_plan(device, M, nseries, &p));
+    const int S = p->S, N1 = p->N1, N2 = p->N2;
+    if (p->mixed || p->P != 1 || N2 % 256 != 0 || !(N1 >= 64 && N1 <= kTilePoints && N2 % (kTilePoints / N1) == 0) || M >= (1LL << 31)) {
+        // (short column transforms, N1 < 64, run the one-tile column kernel: not wired here)
+        if (!(p->P == 1 && !p->mixed && N1 < 64)) return fail(PBH_ERR_UNSUPPORTED, "half-length real_to_complex: plan geometry");
+    }
+    cf* work2 = ensure_work2(p);
+    if (!work2) return fail(PBH_ERR_NOMEM, "half-length real_to_complex: second workspace");
+    // 1. the real series, time fastest = the packed complex series, planar
+    const cf* src = (const cf*)in_dev;
+    if (S > 1) {
+        hipLaunchKernelGGL(k_real_planar, dim3((unsigned)((nreal + 63) / 64), (unsigned)((S + 63) / 64)), dim3(256), 0, st,
+                           (const float*)in_dev, (float*)p->work, nreal, S, nreal);
+        HIPCHECK(hipGetLastError());
+        src = p->work;
+    }
+    // 2. P = FFT_M(p), plan order, in the workspace
+    PBHCHECK(native_forward(p, src, 1, st));
+    // 3. C from P and its mirror, scaled by 1/M, into the second workspace
+    hipLaunchKernelGGL(k_r2c_mirror, dim3((unsigned)((N1 / 2 + 1) * (N2 / 256)), (unsigned)S), dim3(256), 0, st, (const cf*)p->work,
+                       work2, N1, N2, (real)(1.0 / (double)M));
+    HIPCHECK(hipGetLastError());
+    // 4. z = IFFT_M(C): inverse rows, inverse columns (as the dedispersion's second half), sample-major out
+    PBHCHECK(launch_rowfft(N2, work2, p->tw16k, (int64_t)S * N1, st, true));
+    BigTwiddle tw{p->tw_hi, p->tw_lo, p->tw_shift, M - 1};
+    unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
+    if (N1 >= 64) {
+        HIPCHECK(hipMemsetAsync(ctr, 0, 3 * sizeof(unsigned), st));
+        ColpParams cp{work2, M, S, N2, tw, p->tw16k, 0, M, 0, ctr + 1};
+        PBHCHECK(launch_colq<OP_TW_INV>(N1, cp, st));
+    } else {
+        ColSide planar{LAYOUT_PLANAR, M, N2};
+        ColParams c3{work2, work2, planar, planar, LAYOUT_PLANAR, 0, 0, S, N2, (int64_t)S * N2, 0, tw, p->tw16k, 0, M, 0};
+        PBHCHECK(launch_col<OP_TW_INV>(N1, c3, st));
+    }
+    if (S > 1) return launch_reinterleave(work2, (cf*)out_dev, 0, M, S, M, st);
+    HIPCHECK(hipMemcpyAsync(out_dev, work2, sizeof(cf) * (size_t)M, hipMemcpyDeviceToDevice, st));
+    return PBH_OK;
+}
+#endif
 
 // forward stft through k_stft_fwd: power-of-two segments of at most tile/16 points whose tiles cover whole segments (S <=
 // tile/n) or whole channels of one segment (tile/n divides S and holds whole channels)

@@ -57,6 +57,7 @@ int pbh32_device_count(void);
 const char* pbh32_version(void);
 int pbh32_chirp_function(int, void*, double, int64_t, double, double, double, void*, int);
 int pbh32_copy_bench(int, int64_t, int, float*);
+int pbh32_real_to_complex(int, void*, const void*, void*, int64_t, int);
 int pbh32_incoherent(int, void*, const void*, void*, int64_t, int, int, const int64_t*);
 int pbh32_incoherent_series(int, void*, const void*, int64_t, void*, int64_t, int64_t, int, int, int, const int64_t*);
 }
@@ -245,6 +246,9 @@ int pbh_dedisperse_istft(pbh_plan* p, const void* in, int il, int64_t ip, int np
 }
 int pbh_plan_profile(pbh_plan* p, const void* in, void* out, int iters, float* ms, int* nk, const char** names) {
     FORWARD(p, pbh32_plan_profile(P32(p), in, out, iters, ms, nk, names), pbh64_plan_profile(P64(p), in, out, iters, ms, nk, names));
+}
+int pbh_real_to_complex(int device, void* stream, const void* in, void* out, int64_t nreal, int nseries) {
+    return done(PBH_C64, pbh32_real_to_complex(device, stream, in, out, nreal, nseries));
 }
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms) { return done(PBH_C64, pbh32_copy_bench(device, bytes, iters, ms)); }
 

@@ -32,6 +32,11 @@ def real_to_complex(z, axis=0):
     if on_dev:
         t = z.tensor.movedim(axis, 0)
         lead = tuple(t.shape[1:])
+        # float32 data whose half length is a power of two beyond one tile: a HALF-length complex transform (the real series,
+        # time fastest, is the complex series x[2m] + i x[2m+1]) instead of two full-length ones on a complex copy
+        half = _hip.real_to_complex_half(DeviceArray(t.reshape(N, -1).contiguous())) if z.dtype == np.float32 else None
+        if half is not None:
+            return DeviceArray(half.tensor.reshape((N // 2,) + lead).movedim(0, axis).contiguous())
         x = DeviceArray(t.reshape(N, -1).contiguous()).astype(out_dtype)
     else:
         a = np.moveaxis(z, axis, 0)

@@ -96,6 +96,36 @@ class TestRealToComplex:
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,axis", [((1 << 16, 3), 0), ((1 << 17,), 0), ((1 << 18, 4, 2), 0), ((5, 1 << 16), 1),
+                                        ((1 << 21, 16), 0), ((1 << 25, 1), 0), ((1 << 16, 70), 0)])
+def test_real_to_complex_half_length(shape, axis, monkeypatch):
+    """Device float32 data whose half length is a power of two beyond one tile run ``pbh_real_to_complex``: the real series,
+    time fastest, is the complex series x[2m] + i x[2m+1], and two HALF-length transforms with one mirror pass in between
+    give the reference's analytic-signal / mix / decimate result (utils.py:38-65).  Against the oracle, and against the
+    product's full-length route (``PBH_R2C_HALF=0``)."""
+    from pulsarbat_amd import _hip
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape, dtype=np.float32)
+    xd = pb.DeviceArray.from_host(x)
+    calls = []
+    orig = _hip.real_to_complex_half
+    monkeypatch.setattr(_hip, "real_to_complex_half", lambda a: calls.append(orig(a)) or calls[-1])
+    y = real_to_complex(xd, axis=axis)
+    assert calls and calls[-1] is not None, "the half-length path did not run"
+    assert isinstance(y, pb.DeviceArray) and y.dtype == np.complex64
+    if x.size <= 1 << 23:
+        want = orc.real_to_complex(x.astype(np.float64), axis=axis)
+        assert y.shape == want.shape
+        err = np.linalg.norm(np.asarray(y) - want) / np.linalg.norm(want)
+        assert err < 1e-5, f"relative L2 {err:.2e}"
+        assert np.abs(np.asarray(y) - want).max() < 2e-5 * np.abs(want).max()
+    monkeypatch.setenv("PBH_R2C_HALF", "0")
+    y0 = real_to_complex(xd, axis=axis)
+    assert y0.shape == y.shape
+    assert np.linalg.norm(np.asarray(y) - np.asarray(y0)) / np.linalg.norm(np.asarray(y0)) < 2e-6
+
+
+@pytest.mark.gpu
 def test_shifts_any_length():
     """time_shift / freq_shift at lengths that are not powers of two (reference uses N = 1023)."""
     from tests.test_shifts import impulse, sinusoid
