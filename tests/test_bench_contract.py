@@ -33,4 +33,6 @@ def test_bench_json_line():
     assert 0.3 < roof["frac"] < 1.0
     # the path figure says what the five passes move and what that costs at the copy rate measured in the same run
     path = j["path_roofline"]
-    assert 0 < path["floor_ms"] < path["kernel_ms_total"] and 3000 < path["copy_ceiling_GBps"] < 8000
+    # (a plain copy and the five passes are within a few per cent of each other, so no ordering is asserted: boxes differ)
+    assert 0.5 * path["kernel_ms_total"] < path["floor_ms"] < 1.2 * path["kernel_ms_total"]
+    assert 3000 < path["copy_ceiling_GBps"] < 8000

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (PBH_COLQ_PITCH_TEST was a timing-only switch of that experiment; it was removed from the library afterwards -- the results are in profiles/r03_colq_pitch_oop.txt)
 # TIMING experiment: column passes with a padded row pitch (results wrong), in place and ping-pong
 set -o pipefail
 export TMPDIR=/tmp
