@@ -20,6 +20,10 @@ def run(log2n, nchan, npol, dm=56.77, band=400e6, center=1.4e9, nchan_total=None
     x = DeviceArray(torch.view_as_complex(torch.randn((n, nchan, npol, 2), device="cuda") * 0.7071))
     plan = _hip.Plan(n, nchan, npol, start, stop)
     plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, center)
+    if plan.nout <= 0:
+        print(json.dumps({"shape": [n, nchan, npol], "crop": [start, stop], "skipped": "empty valid region at this DM"}), flush=True)
+        plan.close()
+        return
     y = DeviceArray.empty((plan.nout, nchan, npol), np.complex64)
     for _ in range(2):
         plan.dedisperse(x, out=y)
