@@ -225,6 +225,15 @@ int pbh_place(int device, void* hip_stream, int dtype, const void* src_dev, int6
 typedef struct { unsigned char bytes[64]; } pbh_ipc_handle_t;
 #define PBH_NODE_MAX_BYTES (2040ull << 20)
 int pbh_node_alloc(int device, size_t bytes, void** dev_ptr);
+/* The same sharing without the size limit: a physical allocation (hipMemCreate) exported as a POSIX file descriptor and
+ * mapped by every process that holds the descriptor (tools/micro/vmmprobe.hip: a single 3-GiB allocation shared between
+ * two processes, where hipIpcOpenMemHandle hangs beyond 2 GiB).  pbh_node_share_alloc returns the owner's mapping and the
+ * descriptor (the caller sends it to its peers over a Unix socket, SCM_RIGHTS, and closes it); pbh_node_share_import maps
+ * a received descriptor (`bytes` as passed to the owner's call); pbh_node_share_free undoes either.  A destination block
+ * is then ONE contiguous buffer: no row-chunks, no joining copy.                                                       */
+int pbh_node_share_alloc(int device, size_t bytes, void** dev_ptr, int* fd);
+int pbh_node_share_import(int device, int fd, size_t bytes, void** dev_ptr);
+int pbh_node_share_free(int device, void* dev_ptr);
 int pbh_node_free(int device, void* dev_ptr);
 int pbh_node_export(int device, void* dev_ptr, pbh_ipc_handle_t* handle);
 int pbh_node_import(int device, const pbh_ipc_handle_t* handle, void** dev_ptr);

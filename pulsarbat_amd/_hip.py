@@ -105,6 +105,9 @@ SIGNATURES = {
     "pbh_dedisperse_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_float)]),
     "pbh_dedisperse_istft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "pbh_node_share_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "pbh_node_share_import": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pbh_node_share_free": (C.c_int, [C.c_int, C.c_void_p]),
     "pbh_stream_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pbh_dedisperse_stream_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_RawLayout), C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int64),

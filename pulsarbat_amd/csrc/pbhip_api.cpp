@@ -5,7 +5,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 
 #define PBH_DECLARE_IMPL(P)                                                                                     \
@@ -319,6 +323,128 @@ int pbh_node_release(int device, void* dev_ptr) {
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipIpcCloseMemHandle(dev_ptr);
     return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_release: hipIpcCloseMemHandle", e);
+}
+
+// ---- the same sharing through the virtual-memory-management API (round 3) ----------------------------------------------
+// hipIpcOpenMemHandle never returns for allocations beyond 2 GiB on this ROCm stack, which forced destination blocks to be runs of
+// <= 1-GiB chunks and a joining copy afterwards.  A physical allocation made with hipMemCreate and exported as a POSIX file
+// descriptor has no such limit (tools/micro/vmmprobe.hip: one 3-GiB allocation, and a 3-GiB range of three 1-GiB allocations,
+// shared between two processes; 1 GiB: same) -- a destination block is then ONE contiguous buffer of any size.  The descriptor
+// travels between the processes over a Unix socket (SCM_RIGHTS; the Python host does that, pulsarbat_amd/node.py).
+namespace {
+struct SharedMapping { hipMemGenericAllocationHandle_t handle; size_t bytes; };
+std::mutex g_shared_mu;
+std::map<void*, SharedMapping> g_shared;
+
+int shared_map(int device, hipMemGenericAllocationHandle_t h, size_t bytes, void** dev_ptr) {
+    void* va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, bytes, 0, nullptr, 0);
+    if (e != hipSuccess) return hip_fail("hipMemAddressReserve", e);
+    e = hipMemMap(va, bytes, 0, h, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, bytes, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(va, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemAddressFree(va, bytes);
+        return hip_fail("hipMemMap / hipMemSetAccess", e);
+    }
+    std::lock_guard<std::mutex> lk(g_shared_mu);
+    g_shared[va] = SharedMapping{h, bytes};
+    *dev_ptr = va;
+    return PBH_OK;
+}
+size_t shared_round(int device, size_t bytes, hipMemAllocationProp* prop) {
+    prop->type = hipMemAllocationTypePinned;
+    prop->requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    prop->location.type = hipMemLocationTypeDevice;
+    prop->location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) {
+        (void)hipGetLastError();
+        gran = 2u << 20;
+    }
+    return (bytes + gran - 1) / gran * gran;
+}
+}  // namespace
+
+int pbh_node_share_alloc(int device, size_t bytes, void** dev_ptr, int* fd_out) {
+    if (!dev_ptr || !fd_out || bytes == 0) return fail_here(PBH_ERR_INVALID, "pbh_node_share_alloc: bad argument");
+    *dev_ptr = nullptr;
+    *fd_out = -1;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    hipMemAllocationProp prop{};
+    const size_t size = shared_round(device, bytes, &prop);
+    hipMemGenericAllocationHandle_t h;
+    e = hipMemCreate(&h, size, &prop, 0);
+    if (e != hipSuccess) {
+        g_last = -1;
+        g_err = std::string("pbh_node_share_alloc: hipMemCreate(") + std::to_string(size) + "): " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PBH_ERR_NOMEM : PBH_ERR_HIP;
+    }
+    int fd = -1;
+    e = hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0);
+    if (e != hipSuccess) {
+        (void)hipMemRelease(h);
+        return hip_fail("pbh_node_share_alloc: hipMemExportToShareableHandle", e);
+    }
+    const int rc = shared_map(device, h, size, dev_ptr);
+    if (rc != PBH_OK) {
+        close(fd);
+        (void)hipMemRelease(h);
+        return rc;
+    }
+    *fd_out = fd;
+    return PBH_OK;
+}
+
+int pbh_node_share_import(int device, int fd, size_t bytes, void** dev_ptr) {
+    if (!dev_ptr || fd < 0 || bytes == 0) return fail_here(PBH_ERR_INVALID, "pbh_node_share_import: bad argument");
+    *dev_ptr = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    hipMemAllocationProp prop{};
+    const size_t size = shared_round(device, bytes, &prop);
+    hipMemGenericAllocationHandle_t h;
+    // The HIP runtimes in use disagree about `osHandle`: 7.0 (the one torch 2.10+rocm7.0 bundles and loads first) takes a POINTER to
+    // the descriptor and dies with SIGSEGV on CUDA's form, the descriptor's value cast to a pointer; 7.2 takes the value.  A pointer
+    // handed to a value-taking runtime is merely a bad descriptor number (an error), the reverse is a crash: pointer form first.
+    int fdv = fd;
+    e = hipMemImportFromShareableHandle(&h, (void*)&fdv, hipMemHandleTypePosixFileDescriptor);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMemImportFromShareableHandle(&h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+    }
+    if (e != hipSuccess) return hip_fail("pbh_node_share_import: hipMemImportFromShareableHandle", e);
+    const int rc = shared_map(device, h, size, dev_ptr);
+    if (rc != PBH_OK) (void)hipMemRelease(h);
+    return rc;
+}
+
+int pbh_node_share_free(int device, void* dev_ptr) {
+    if (!dev_ptr) return PBH_OK;
+    SharedMapping m;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_mu);
+        auto it = g_shared.find(dev_ptr);
+        if (it == g_shared.end()) return fail_here(PBH_ERR_INVALID, "pbh_node_share_free: not a shared mapping of this process");
+        m = it->second;
+        g_shared.erase(it);
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // peers may only just have finished writing
+    hipError_t e2 = hipMemUnmap(dev_ptr, m.bytes);
+    if (e == hipSuccess) e = e2;
+    e2 = hipMemAddressFree(dev_ptr, m.bytes);
+    if (e == hipSuccess) e = e2;
+    e2 = hipMemRelease(m.handle);
+    if (e == hipSuccess) e = e2;
+    return e == hipSuccess ? PBH_OK : hip_fail("pbh_node_share_free", e);
 }
 
 }  // extern "C"

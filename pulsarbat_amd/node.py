@@ -9,13 +9,14 @@ torch.distributed is used for what it is here for: exchanging the 64-byte handle
 """
 
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _hip
 from .device import DeviceArray
 
-__all__ = ["NodeBuffer", "PeerBuffer", "ChannelGather", "GatherError", "MAX_NODE_BYTES"]
+__all__ = ["NodeBuffer", "PeerBuffer", "SharedBuffer", "SharedPeer", "ChannelGather", "GatherError", "MAX_NODE_BYTES"]
 
 # The largest buffer a peer has been SEEN to map (tools/ipc_probe.py: 2040 MiB maps in 0.1 ms, 2056 MiB never returns from
 # hipIpcOpenMemHandle).  pbh_node_alloc refuses anything larger; ChannelGather uses 1-GiB row-chunks.
@@ -96,6 +97,134 @@ class PeerBuffer:
     __del__ = close
 
 
+class SharedBuffer:
+    """A device buffer of ANY size that the node's other ranks can map (``pbh_node_share_alloc``: hipMemCreate + a POSIX file
+    descriptor).  ``fd`` is the descriptor to hand to the peers (``send_fds``); ``close_fd()`` once they have it."""
+
+    def __init__(self, shape, dtype, device):
+        _hip._require_device()
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+        self.nbytes = max(int(np.prod(self.shape)) * self.dtype.itemsize, 16)
+        ptr, fd = C.c_void_p(), C.c_int(-1)
+        _hip._check(_hip.lib().pbh_node_share_alloc(self.device, self.nbytes, C.byref(ptr), C.byref(fd)))
+        self.ptr, self.fd = ptr.value, fd.value
+        self._array = None
+
+    def close_fd(self):
+        fd, self.fd = getattr(self, "fd", -1), -1
+        if fd >= 0:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+
+    @property
+    def array(self):
+        if self._array is None:
+            import torch
+            t = torch.as_tensor(_Cai(self.ptr, self.shape, self.dtype, self), device=torch.device("cuda", self.device))
+            if int(np.prod(self.shape)) and t.data_ptr() != self.ptr:
+                raise _hip.HipError("torch copied the shared buffer instead of viewing it")
+            self._array = DeviceArray(t)
+        return self._array
+
+    def close(self):
+        self.close_fd()
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                _hip.lib().pbh_node_share_free(self.device, C.c_void_p(ptr))
+            except Exception:   # interpreter shutdown
+                pass
+
+    __del__ = close
+
+
+class SharedPeer:
+    """Another rank's :class:`SharedBuffer`, mapped from its file descriptor (``pbh_node_share_import``)."""
+
+    def __init__(self, fd, nbytes, device):
+        self.device = int(device)
+        ptr = C.c_void_p()
+        _hip._check(_hip.lib().pbh_node_share_import(self.device, int(fd), int(nbytes), C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def close(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                _hip.lib().pbh_node_share_free(self.device, C.c_void_p(ptr))
+            except Exception:
+                pass
+
+    __del__ = close
+
+
+def _exchange_fds(group, my_fds, timeout=60.0):
+    """Every rank that has file descriptors to share (``my_fds``, may be empty) serves them on a Unix socket; every rank
+    fetches the descriptors of every other serving rank.  Returns ``{rank: [fd, ...]}`` (the caller owns and closes them).
+    Descriptors cannot travel through torch.distributed: SCM_RIGHTS over a Unix-domain socket is the kernel's way."""
+    import os
+    import socket
+    import tempfile
+    import threading
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    path, server = None, None
+    if my_fds:
+        path = os.path.join(tempfile.gettempdir(), f"pbh_gather_{os.getpid()}_{id(my_fds):x}.sock")
+        server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        server.bind(path)
+        server.listen(world)
+        server.settimeout(timeout)
+    paths = [None] * world
+    dist.all_gather_object(paths, (path, len(my_fds)), group=group)
+    errors = []
+
+    def serve():
+        try:
+            for _ in range(world - 1):
+                conn, _ = server.accept()
+                with conn:
+                    conn.settimeout(timeout)
+                    conn.recv(1)
+                    socket.send_fds(conn, [b"f"], list(my_fds))
+        except Exception as exc:
+            errors.append(exc)
+
+    th = None
+    if server is not None and world > 1:
+        th = threading.Thread(target=serve, daemon=True)
+        th.start()
+    got = {}
+    try:
+        for r, (pth, nfd) in enumerate(paths):
+            if r == rank or pth is None:
+                continue
+            with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as c:
+                c.settimeout(timeout)
+                c.connect(pth)
+                c.send(b"r")
+                _, fds, _, _ = socket.recv_fds(c, 16, nfd)
+                if len(fds) != nfd:
+                    raise _hip.HipError(f"rank {r} sent {len(fds)} descriptors, {nfd} expected")
+                got[r] = list(fds)
+    finally:
+        if th is not None:
+            th.join(timeout)
+        if server is not None:
+            server.close()
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    if errors:
+        raise errors[0]
+    return got
+
+
 class GatherError(_hip.HipError):
     """A step of the collective gather failed on some rank; raised on EVERY rank of the group."""
 
@@ -104,14 +233,16 @@ class ChannelGather:
     """Gather of channel-sharded results by direct writes into the destination ranks' full-band blocks.
 
     ``mode="all"``: every rank ends up with the full ``(nout, nchan_total, npol)`` block (what ``gather=True`` returns
-    on every rank); ``mode="root"``: only ``root`` does.  A destination's block is a run of ROW-CHUNKS, each its own
-    allocation of at most ``chunk_bytes`` (1 GiB): mapping an allocation larger than 2 GiB into a peer process hangs in
-    this ROCm stack's IPC (measured between two processes on ONE device: 2040 MiB maps in 0.1 ms, 2056 MiB never returns;
-    the cross-device case is unobserved), and the blocks in question are 2 - 17 GB.  Every rank runs its plan once: the
-    pipeline's last kernel writes the rank's channel slice into the chunks of the first destination
-    (``pbh_dedisperse_slices``; its own chunks when it is a destination), and ``pbh_place`` pushes the slice from there to
-    the other destinations' chunks -- ONE STREAM PER DESTINATION, so that in ``mode="all"`` a rank drives its seven xGMI
-    links at once (the links are point to point: a single stream keeps one of them busy at a time).
+    on every rank); ``mode="root"``: only ``root`` does.  A destination's block is ONE contiguous buffer shared through a
+    file descriptor (:class:`SharedBuffer`: hipMemCreate + SCM_RIGHTS; any size -- tools/micro/vmmprobe.hip shares a 3-GiB
+    allocation between two processes).  Where that cannot be set up, all ranks fall back together to the older form: a run
+    of ROW-CHUNKS, each its own hipMalloc of at most ``chunk_bytes`` (1 GiB) shared through hipIpc handles -- mapping an
+    allocation larger than 2 GiB that way hangs in this ROCm stack's IPC (measured between two processes on ONE device:
+    2040 MiB maps in 0.1 ms, 2056 MiB never returns; the cross-device case is unobserved) -- joined into one array
+    afterwards.  Every rank runs its plan once: the pipeline's last kernel writes the rank's channel slice into the first
+    destination's block (``pbh_dedisperse_slices``; its own when it is a destination), and ``pbh_place`` pushes the slice
+    from there to the other destinations -- ONE STREAM PER DESTINATION, so that in ``mode="all"`` a rank drives its seven
+    xGMI links at once (the links are point to point: a single stream keeps one of them busy at a time).
 
     Reusable for repeated calls of one geometry (a stream of blocks): chunks and mappings are set up once
     (``shard.coherent_dedispersion_sharded`` keeps its gathers in a cache next to the plans).  The chunks are DOUBLE
@@ -125,10 +256,9 @@ class ChannelGather:
     """
 
     def __init__(self, nout, nchan_local, npol, dtype, device, group=None, mode="all", root=0, chunk_bytes=None):
-        import os
         import torch
         import torch.distributed as dist
-        if chunk_bytes is None:   # PBH_GATHER_CHUNK_BYTES: tests force many chunks at small sizes
+        if chunk_bytes is None:   # PBH_GATHER_CHUNK_BYTES: tests force the chunked form with many chunks at small sizes
             chunk_bytes = int(os.environ.get("PBH_GATHER_CHUNK_BYTES", 1 << 30))
         if mode not in ("all", "root"):
             raise ValueError("mode must be 'all' or 'root'")
@@ -144,6 +274,57 @@ class ChannelGather:
         self.chan_lo = sum(self.counts[:self.rank])
         self.nchan_local = int(nchan_local)
         self.is_dest = mode == "all" or self.rank == self.root
+        # Destination blocks: ONE contiguous buffer per destination and buffer set, shared through file descriptors
+        # (SharedBuffer: no size limit, no joining copy).  If that cannot be set up on some rank -- all ranks then agree on
+        # it -- the older form: row-chunks of <= 1 GiB shared through hipIpc handles (NodeBuffer) and joined afterwards.
+        self.shared = os.environ.get("PBH_GATHER_SHARED", "1") != "0" and "PBH_GATHER_CHUNK_BYTES" not in os.environ
+        if self.shared and not self._setup_shared():
+            self.shared = False
+        if not self.shared:
+            self._setup_chunks(chunk_bytes)
+
+    def _setup_shared(self):
+        """The contiguous form.  Returns False (on every rank) when it is not available; raises nothing."""
+        import torch.distributed as dist
+        self.part_rows = [0, self.nout] if self.nout > 0 else [0]
+        shape = (self.nout, self.nchan_total, self.npol)
+        err, fds = None, []
+        try:
+            if self.is_dest and self.nout > 0:
+                self.own = [[SharedBuffer(shape, self.dtype, self.device)] for _ in range(2)]
+                fds = [bufs[0].fd for bufs in self.own]
+            elif self.is_dest:
+                self.own = [[], []]
+        except Exception as exc:
+            err = exc
+        if self._agree(err is not None):
+            self._release(free=True)
+            return False
+        try:
+            got = _exchange_fds(self.group, fds) if self.world > 1 else {}
+            nbytes = max(int(np.prod(shape)) * self.dtype.itemsize, 16)
+            for r, rfds in got.items():
+                try:
+                    self.peers[r] = [[SharedPeer(fd, nbytes, self.device)] for fd in rfds]
+                finally:
+                    for fd in rfds:
+                        os.close(fd)
+        except Exception as exc:
+            err = exc
+        finally:
+            for bufs in (self.own or []):
+                for b in bufs:
+                    b.close_fd()
+        if self._agree(err is not None):
+            self._release(free=False)
+            self._agree(False)          # nobody still maps this rank's buffers when they are freed
+            self._release(free=True)
+            return False
+        return True
+
+    def _setup_chunks(self, chunk_bytes):
+        import torch.distributed as dist
+        group = self.group
         row_bytes = self.row_elems * self.dtype.itemsize
         rows_per = max(1, min(int(chunk_bytes), MAX_NODE_BYTES) // max(row_bytes, 1))
         self.part_rows = list(range(0, self.nout, rows_per)) + [self.nout] if self.nout > 0 else [0]
@@ -196,9 +377,9 @@ class ChannelGather:
         """Dedisperse this rank's shard ``x`` with ``plan`` and deliver the slice to every destination.
         Returns the full-band DeviceArray on destination ranks, None elsewhere.  Collective.
 
-        ``copy=False`` returns the destination's row-chunks themselves (a list of DeviceArrays, rows ``part_rows[i] :
-        part_rows[i+1]``) instead of joining them into one array: no extra HBM pass, but the chunks are overwritten by the
-        next-but-one ``run`` of this gather."""
+        ``copy=False`` returns the destination's own buffer (contiguous form: the full-band DeviceArray itself, no extra HBM
+        pass at all; chunked form: the list of row-chunks, rows ``part_rows[i] : part_rows[i+1]``) instead of a copy; it is
+        overwritten by the next-but-one ``run`` of this gather."""
         import torch
         lib = _hip.lib()
         gen = self._runs & 1
@@ -237,6 +418,8 @@ class ChannelGather:
         if self.own is None:
             return None
         chunks = [b.array for b in self.own[gen]]
+        if self.shared and chunks:   # one contiguous buffer: nothing to join
+            return chunks[0] if not copy else DeviceArray(chunks[0].tensor.clone())
         if not copy:
             return chunks
         full = DeviceArray.empty((self.nout, self.nchan_total, self.npol), self.dtype, device=self.device)

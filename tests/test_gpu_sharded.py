@@ -274,6 +274,49 @@ def test_sharded_hip_world2_on_one_gpu(nchan):
         assert np.array_equal(again, full)
 
 
+def _shared_child(dupfd, nbytes, q):
+    import os
+    import torch
+    from pulsarbat_amd.node import SharedPeer, _Cai
+    fd = dupfd.detach()                      # the descriptor arrives over a Unix socket (multiprocessing's resource sharer)
+    peer = SharedPeer(fd, nbytes, 0)
+    os.close(fd)
+    t = torch.as_tensor(_Cai(peer.ptr, (nbytes // 4,), np.float32, peer), device="cuda:0")
+    seen = float(t[::4097].double().sum().item())
+    t.mul_(2.0)
+    torch.cuda.synchronize()
+    q.put(seen)
+    del t
+    peer.close()
+
+
+def test_shared_buffer_beyond_two_gib():
+    """A destination block of the gather is one contiguous `SharedBuffer` (hipMemCreate + a POSIX file descriptor): 2.5 GiB
+    mapped by a second process, which reads the owner's values and writes its own -- a size at which hipIpcOpenMemHandle
+    never returns on this stack (tools/ipc_probe.py), hence the <= 1-GiB row-chunks of the older form."""
+    import multiprocessing as mp
+    from multiprocessing import reduction
+    import torch
+    from pulsarbat_amd.node import SharedBuffer
+    n = (5 << 29) // 4
+    buf = SharedBuffer((n,), np.float32, 0)
+    t = buf.array.tensor
+    t.copy_(torch.arange(n, device="cuda", dtype=torch.float32) % 1000)
+    torch.cuda.synchronize()
+    want = float(t[::4097].double().sum().item())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_shared_child, args=(reduction.DupFd(buf.fd), buf.nbytes, q))
+    p.start()
+    seen = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and seen == want
+    torch.cuda.synchronize()
+    assert float(t[::4097].double().sum().item()) == 2 * want      # the peer's writes are visible to the owner
+    del t
+    buf.close()
+
+
 def _rccl_world1_worker(port, q):
     """Every RCCL line of the sharded path, once, on a one-rank "nccl" group (the first GPU call of this process is the
     process group's own)."""
