@@ -172,9 +172,10 @@ def _exchange_fds(group, my_fds, timeout=60.0):
     import threading
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    path, server = None, None
+    path, server, private = None, None, None
     if my_fds:
-        path = os.path.join(tempfile.gettempdir(), f"pbh_gather_{os.getpid()}_{id(my_fds):x}.sock")
+        private = tempfile.mkdtemp(prefix="pbh_gather_")   # mode 0700: only this user's processes can reach the socket
+        path = os.path.join(private, "fds.sock")
         server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         server.bind(path)
         server.listen(world)
@@ -216,10 +217,11 @@ def _exchange_fds(group, my_fds, timeout=60.0):
             th.join(timeout)
         if server is not None:
             server.close()
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            for undo, what in ((os.unlink, path), (os.rmdir, private)):
+                try:
+                    undo(what)
+                except OSError:
+                    pass
     if errors:
         raise errors[0]
     return got
