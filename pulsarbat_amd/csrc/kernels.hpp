@@ -611,6 +611,12 @@ struct RowpParams {
     int cP = 1;          // phase rows stored in split order cP x (N1/cP), data rows in natural order (RowParams::cP)
     int phase16 = 0;     // the phase rows are stored in k_rowp16's order (ChirpParams::phase16): k_rowp16 runs the pass
     cf* out = nullptr;   // k_rowp16: rows are stored here (same geometry) instead of in place -- the ping-pong schedule
+    // k_rowp16<.., OTF>: the phase is not read but computed where it is used, in float64 as k_chirp does (aux_kernels.hpp):
+    // f = chan_freq[chan] + bin * inv_ndt, phi = coeff f (1/f_ref - 1/f)^2 -- 4.8 -> 4.3 GB per launch for ~15 float64
+    // instructions per bin and pol pair
+    const double* chan_freq = nullptr;
+    double coeff = 0, inv_ndt = 0, inv_ref = 0;
+    int64_t N = 0;
 };
 
 template <int M, int R>
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp(RowpParams p) {
 // stores per thread during which the wave issues nothing else) but stay in registers and leave one per tick of the NEXT tile's
 // forward transform, in the registers the next tile's samples vacated (k_colq's scheme; the loads already ride in the inverse
 // transform's ticks): memory traffic in both halves of an iteration, no burst.
-template <int R, int ABL = 0, bool DS = false>
+template <int R, int ABL = 0, bool DS = false, bool OTF = false>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
     constexpr int M = kTilePoints;
     static_assert(M == 16384 && R == 32, "k_rowp16: 2^14-point rows, 32 points per thread");
@@ -816,6 +822,27 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
                 const uint32_t ch = u / (uint32_t)p.N1, k1d = u - ch * (uint32_t)p.N1;
                 up = ch * (uint32_t)p.N1 + (k1d % (uint32_t)p.cP) * (uint32_t)(p.N1 / p.cP) + k1d / (uint32_t)p.cP;
             }
+            if constexpr (OTF) {
+                // this thread's bins of the row: k2 = tau + 512 i, k = k1 + N1 k2, in numpy.fft.fftfreq order
+                const uint32_t ch = up / (uint32_t)p.N1, k1 = up - ch * (uint32_t)p.N1;
+                const double fc = p.chan_freq[ch];
+                const int half = (int)((p.N - 1) / 2), n = (int)p.N;   // (N < 2^31: host-checked)
+                int t2 = tau;
+                asm volatile("" : "+v"(t2));   // not loop-invariant for the compiler: else 32 bin indices are hoisted out of the persistent loop
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int k = (int)k1 + p.N1 * (t2 + MR * i);
+                    const double f = fma((double)(k <= half ? k : k - n), p.inv_ndt, fc);
+                    double r = __builtin_amdgcn_rcp(f);          // + two Newton steps: full float64 accuracy
+                    r = fma(r, fma(-f, r, 1.0), r);
+                    r = fma(r, fma(-f, r, 1.0), r);
+                    const double dd = p.inv_ref - r;
+                    const double phi = (p.coeff * f) * (dd * dd);
+                    ph[i] = (float)(__builtin_rint(phi) - phi);   // chirp = exp(2 pi i ph), ph = -(phi mod 1)
+                    // four independent chains at a time: left alone the scheduler interleaves all 32 and spills 220 B/lane
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             const rsrc_t rp = make_rsrc(p.phase + (int64_t)up * M, (uint32_t)(M * sizeof(float)));
 #pragma unroll
             for (int j = 0; j < R / 4; ++j) {   // the row is stored in this order (ChirpParams::phase16): 8 x 16 bytes per thread
@@ -824,6 +851,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
                 ph[4 * j + 1] = __uint_as_float(x.y);
                 ph[4 * j + 2] = __uint_as_float(x.z);
                 ph[4 * j + 3] = __uint_as_float(x.w);
+            }
             }
         }
         // forward: 16 (pair-adjacent bases), 32, 32 -> natural distribution tau + 512 i

@@ -273,6 +273,7 @@ struct pbh_plan {
     bool rowmix = false;
     MixTable mixR;
     double stream_stats[PBH_STREAM_NSTATS] = {};   // of the last streaming call (pbh_stream_stats)
+    double gen_coeff = 0, gen_inv_ndt = 0, gen_inv_ref = 0;   // parameters of the generated chirp (k_rowp16's on-the-fly phase)
 };
 
 static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
@@ -506,6 +507,8 @@ static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     static const bool defer = [] { const char* e = getenv("PBH_ROW16_DEFER"); return e ? atoi(e) != 0 : false; }();   // deferred stores (A/B)
     if (prm.phase16 && M == kTilePoints) {
         if (nofft) return launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+        if (prm.chan_freq && prm.cP == 1)
+            return launch_tile_kernel(k_rowp16<PBH_R, 0, false, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         return defer ? launch_tile_kernel(k_rowp16<PBH_R, 0, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16)
                      : launch_tile_kernel(k_rowp16<PBH_R, 0, false>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
     }
@@ -1164,6 +1167,14 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
             rpp.cP = chirp_split;
             rpp.phase16 = p->phase16;
+            static const bool otf = [] { const char* e = getenv("PBH_ROW_OTF"); return e ? atoi(e) != 0 : false; }();
+            if (otf && p->phase16 && chirp_split == 1 && is_pow2(p->N)) {   // phase computed in the kernel (A/B switch)
+                rpp.chan_freq = p->chan_freq;
+                rpp.coeff = p->gen_coeff;
+                rpp.inv_ndt = p->gen_inv_ndt;
+                rpp.inv_ref = p->gen_inv_ref;
+                rpp.N = p->N;
+            }
             if (workB) {
                 rpp.data = workB;
                 rpp.out = work;
@@ -2044,6 +2055,9 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
         p->has_phase = true;
     }
 #endif
+    p->gen_coeff = cp.coeff;
+    p->gen_inv_ndt = cp.inv_ndt;
+    p->gen_inv_ref = cp.inv_ref;
     hipLaunchKernelGGL(k_chirp, dim3(2048), dim3(256), 0, p->stream, cp);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));  // chan_freq_hz is a borrowed host buffer
