@@ -104,7 +104,7 @@ def test_7smooth_lengths_full_size_all_series(n):
     assert err.shape == (16,) and err.max() < RTOL_L2, f"per-series relative L2: {err}"
 
 
-@pytest.mark.parametrize("rank", [0, 5])
+@pytest.mark.parametrize("rank", [0, 3, 5, 7])
 def test_config2_rank_share_full_size(one_rank_group, rank):
     """BASELINE configs[2]: 64 channels of 6.25 MHz over 8 GPUs; this is rank `rank`'s share (8 channels x 2 pol x
     2^24) through the sharded entry point with the real plan, full-band crop [176051, 16505967)."""
@@ -126,14 +126,15 @@ def test_config2_rank_share_full_size(one_rank_group, rank):
     assert err.max() < RTOL_L2, f"per-series relative L2: {err}"
 
 
-def test_config4_rank_share_full_size(one_rank_group):
+@pytest.mark.parametrize("rank", [2, 7])
+def test_config4_rank_share_full_size(one_rank_group, rank):
     """BASELINE configs[4]: the configs[2] geometry at DM 1000 with the fused Stokes-I detect + 1024x time scrunch
     (crop [3101118, 11999198), 8 898 080 valid samples -> (8689, nchan); one rank's 8 channels)."""
-    n, nchan_total, npol, fc, dm, world, rank = 1 << 24, 64, 2, 1.4e9, 1000.0, 8, 2
+    n, nchan_total, npol, fc, dm, world = 1 << 24, 64, 2, 1.4e9, 1000.0, 8
     sr = 400e6 / nchan_total
     sl = shard.channel_slice(nchan_total, world, rank)
     freqs = orc.channel_freqs(fc, sr, nchan_total)[sl]
-    xt = device_block((n, 8, npol), 20260005)
+    xt = device_block((n, 8, npol), 20260005 + rank)
     zl = pb.DualPolarizationSignal(pb.DeviceArray(xt), sample_rate=sr * u.Hz, center_freq=float(freqs.mean()) * u.Hz,
                                    pol_type="linear")
     lo, hi = (fc - 200e6) * u.Hz, (fc + 200e6) * u.Hz
