@@ -303,7 +303,7 @@ def main():
 
     # optional: the one real exchange step of the sharded path, an all-gather of the outputs along the channel
     # axis (results are left sharded by default; the gather is timed separately)
-    gather_ms = None
+    gather_ms, gather_form = None, None
     if distributed and args.gather:
         try:
             from pulsarbat_amd.node import ChannelGather
@@ -314,8 +314,9 @@ def main():
             barrier()
             mark("gather: timed run")
             t1 = time.perf_counter()
-            g.run(plan, x)     # dedispersion + delivery of the slice to the destination block(s) + closing barrier
+            g.run(plan, x)     # dedispersion + delivery of the slice to the destination block(s) + closing collective
             gather_ms = (time.perf_counter() - t1) * 1e3
+            gather_form = "one contiguous shared buffer per destination" if g.shared else "hipIpc row-chunks + join"
             g.close()
             del g
         except Exception as exc:   # never lose the main line to the optional figure
@@ -403,7 +404,7 @@ def main():
         if series_major is not None:
             result["series_major_io"] = series_major
         if gather_ms is not None:
-            result["step_with_gather_ms"] = {"mode": args.gather, "ms": gather_ms}
+            result["step_with_gather_ms"] = {"mode": args.gather, "ms": gather_ms, "destinations": gather_form}
         if world == 1 and not args.no_extras and args.log2n == 24:
             del x, y, z_local
             torch.cuda.empty_cache()
