@@ -52,23 +52,39 @@ __device__ __forceinline__ int64_t row_bin(int64_t e2, int N2, int perm_w, const
 }
 
 __global__ __launch_bounds__(256) void k_chirp(ChirpParams p) {
-    const int64_t total = p.N * p.nchan;
-    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < total;
-         d += (int64_t)gridDim.x * blockDim.x) {
-        const int chan = (int)(d / p.N);
-        const int64_t e = d - (int64_t)chan * p.N;
-        const int64_t r = e / p.N2, k2 = row_bin(e - r * p.N2, p.N2, p.perm_w, p.row_perm);
-        const int64_t k = row_k1(r, p.P, p.N1) + (int64_t)p.N1 * k2;
-        const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
-        const double f = p.chan_freq[chan] + (double)bin * p.inv_ndt;
-        const double dd = p.inv_ref - 1.0 / f;
-        const double phi = (p.coeff * f) * (dd * dd);
-        const double fr = phi - rint(phi);
-        double sn, cs;
-        sincospi(2.0 * fr, &sn, &cs);
-        // the reference rounds the transfer function to complex64 (dedispersion.py:23) for both data dtypes
-        p.out[d] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
-        if (p.phase) p.phase[phase_index(d, p.N2, p.phase16)] = (float)(-fr);   // chirp = exp(2 pi i phase): what k_rowp feeds to v_cos / v_sin
+    // A unit of work is 1024 consecutive positions of one row (chan, r): its indices cost two 64-bit divisions per unit, not
+    // three per element (the grid-stride form spent more time on index arithmetic than on the float64 phase).
+    const int64_t nrow = p.N / p.N2;
+    const int chunks = (p.N2 + 1023) / 1024;
+    const int64_t units = (int64_t)p.nchan * nrow * chunks;
+    for (int64_t uidx = blockIdx.x; uidx < units; uidx += gridDim.x) {
+        const int c = (int)(uidx % chunks);
+        const int64_t cr = uidx / chunks;
+        const int chan = (int)(cr / nrow);
+        const int64_t r = cr - (int64_t)chan * nrow;
+        const double fcen = p.chan_freq[chan];
+        const int64_t k1 = row_k1(r, p.P, p.N1);
+        const int64_t rowbase = (int64_t)chan * p.N + r * p.N2;
+        const int e_end = (c + 1) * 1024 < p.N2 ? (c + 1) * 1024 : p.N2;
+        for (int e2 = c * 1024 + (int)threadIdx.x; e2 < e_end; e2 += 256) {
+            const int64_t k2 = row_bin(e2, p.N2, p.perm_w, p.row_perm);
+            const int64_t k = k1 + (int64_t)p.N1 * k2;
+            const int64_t bin = (k <= (p.N - 1) / 2) ? k : k - p.N;  // numpy.fft.fftfreq ordering
+            const double f = fcen + (double)bin * p.inv_ndt;
+            const double dd = p.inv_ref - 1.0 / f;
+            const double phi = (p.coeff * f) * (dd * dd);
+            const double fr = phi - rint(phi);
+            if (p.out) {   // (null: the plan's row pass reads the phase only; the complex form is made when somebody asks for it)
+                double sn, cs;
+                sincospi(2.0 * fr, &sn, &cs);
+                // the reference rounds the transfer function to complex64 (dedispersion.py:23) for both data dtypes
+                p.out[rowbase + e2] = make_cf((real)(float)cs * p.scale, (real)(float)(-sn) * p.scale);
+            }
+            if (p.phase) {   // chirp = exp(2 pi i phase): what k_rowp feeds to v_cos / v_sin
+                const int tau = e2 & 511, i = e2 >> 9;
+                p.phase[rowbase + (p.phase16 ? (((i >> 2) << 11) + (tau << 2) + (i & 3)) : e2)] = (float)(-fr);
+            }
+        }
     }
 }
 

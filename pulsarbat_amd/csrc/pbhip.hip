@@ -274,6 +274,7 @@ struct pbh_plan {
     MixTable mixR;
     double stream_stats[PBH_STREAM_NSTATS] = {};   // of the last streaming call (pbh_stream_stats)
     double gen_coeff = 0, gen_inv_ndt = 0, gen_inv_ref = 0;   // parameters of the generated chirp (k_rowp16's on-the-fly phase)
+    bool chirp_lazy = false;   // the generated chirp exists as phase rows only; `chirp` is filled by materialize_chirp on demand
 };
 
 static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
@@ -2035,6 +2036,18 @@ int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* info) {
 // ---- chirp --------------------------------------------------------------------------------------------------
 static real inv_n(const pbh_plan* p) { return (real)(1.0 / (double)p->N); }
 
+// the complex64 form of a generated chirp that so far exists as phase rows only (pbh_chirp_generate)
+static int materialize_chirp(pbh_plan* p) {
+    if (!p->chirp_lazy) return PBH_OK;
+    ChirpParams cp{p->chirp, p->chan_freq, p->gen_coeff, p->gen_inv_ndt, p->gen_inv_ref, p->N, p->N1, p->N2, p->nchan, inv_n(p), p->perm_w};
+    cp.P = p->P;
+    cp.row_perm = p->rowmix ? p->mixR.perm : nullptr;
+    hipLaunchKernelGGL(k_chirp, dim3(2048), dim3(256), 0, p->stream, cp);
+    HIPCHECK(hipGetLastError());
+    p->chirp_lazy = false;
+    return PBH_OK;
+}
+
 int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* chan_freq_hz, double ref_freq_hz) {
     if (!p || !chan_freq_hz) return fail(PBH_ERR_INVALID, "NULL argument");
     if (!(dt_s > 0)) return fail(PBH_ERR_INVALID, "dt must be positive");
@@ -2054,6 +2067,14 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
         p->phase16 = cp.phase16 != 0;
         p->has_phase = true;
     }
+    // The fused row pass of such a plan reads the PHASE rows only.  The complex64 chirp (a float64 sincospi and 8 bytes written
+    // per bin: 0.6 of the 0.8 ms this call took at config 2) is made when somebody asks for it -- pbh_chirp_download, i.e.
+    // chirp_from_signal -- and not for every new DM of a search.  PBH_CHIRP_LAZY=0: always both.
+    static const bool lazy_on = [] { const char* e = getenv("PBH_CHIRP_LAZY"); return e ? atoi(e) != 0 : true; }();
+    p->chirp_lazy = lazy_on && p->has_phase && row_phase_enabled();
+    if (p->chirp_lazy) cp.out = nullptr;
+#else
+    p->chirp_lazy = false;
 #endif
     p->gen_coeff = cp.coeff;
     p->gen_inv_ndt = cp.inv_ndt;
@@ -2096,6 +2117,7 @@ int pbh_chirp_upload_as(pbh_plan* p, const void* chirp_c64, int chirp_dtype, int
     HIPCHECK(hipGetLastError());
     if (loc == PBH_HOST) HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
+    p->chirp_lazy = false;
     p->has_phase = false;  // a user-supplied chirp is applied as the complex64 values it is
     PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
@@ -2105,6 +2127,7 @@ int pbh_chirp_download(pbh_plan* p, void* chirp_c64, int loc) {
     if (!p || !chirp_c64) return fail(PBH_ERR_INVALID, "NULL argument");
     if (!p->has_chirp) return fail(PBH_ERR_STATE, "plan has no chirp yet");
     HIPCHECK(hipSetDevice(p->device));
+    PBHCHECK(materialize_chirp(p));
     const size_t bytes = sizeof(float2) * (size_t)p->nchan * p->N;
     float2* dst = (float2*)chirp_c64;
     if (loc == PBH_HOST) {
@@ -2146,6 +2169,7 @@ int pbh_chirp_special(pbh_plan* p, const double* arg /*[nchan]*/, int mode) {
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(p->stream));
     p->has_chirp = true;
+    p->chirp_lazy = false;
     p->has_phase = phase;
     PBHCHECK(rebuild_circular_filter(p));
     return PBH_OK;
