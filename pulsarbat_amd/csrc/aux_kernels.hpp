@@ -961,6 +961,62 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
     }
 }
 
+// ---- second half of the detect tail fused into the inverse column pass (k_colq<.., DET>) ---------------------------
+// The column pass left, per (series, 16-column group g, row r), the power summed over the group's columns
+// (ColpParams::det_part / det_side).  Output sample o covers times [start + o ns, start + (o + 1) ns), t = r N2 + n2:
+// ns / 16 consecutive groups of one row (the run may continue in the next row), plus -- when start is not a multiple of 16
+// -- the columns behind the boundary of its first group (det_side) and the columns before the boundary of the group
+// after its last one (what det_part holds for a group with a boundary).  One thread per (row, interval of the row,
+// channel); consecutive threads follow the partial sums' row order (row = x / R + MR (x % R)): coalesced reads.
+//   mode 0: out[o][chan][pol];  mode 1 (Stokes I): out[o][chan], polarisations added.
+__global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ part, const real* __restrict__ side,
+                                                       real* __restrict__ out, int N2, int M, int R, int ns, int64_t start,
+                                                       int64_t nout, int nchan, int npol, int mode) {
+    // 64 rows x 4 quarters of an output's run of groups per workgroup (the quarters meet in LDS)
+    __shared__ real sh[4][64];
+    const int xl = threadIdx.x & 63, qu = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + xl;
+    const int kk = blockIdx.y, chan = blockIdx.z;
+    const int MR = M / R;
+    const int r0 = x / R + MR * (x % R);
+    const int bmod = (int)(start % ns), bcol = bmod & 15;
+    const int64_t t0 = (int64_t)r0 * N2 + (int64_t)kk * ns + bmod;
+    const int64_t o = t0 >= start ? (t0 - start) / ns : -1;
+    const bool live = x < M && o >= 0 && o < nout;
+    const int ngrp = N2 / 16, nb = N2 / ns, nj = ns / 16 + (bcol != 0);
+    // groups g0 .. of row r0, then (when the run crosses the end of the row) groups 0 .. of row r0 + 1; the first one
+    // comes from `side` when the boundary lies inside it
+    const int g0 = (kk * ns + bmod - bcol) / 16;
+    const int n0 = min(nj, ngrp - g0);
+    const int xn = ((r0 + 1) % MR) * R + (r0 + 1) / MR;
+    const int per = (nj + 3) / 4, ja = max(1, qu * per), jb = min(nj, (qu + 1) * per);
+    real tot = 0;
+    for (int pp = 0; pp < npol; ++pp) {
+        const int s = chan * npol + pp;
+        const real* ps = part + (int64_t)s * ngrp * M;
+        real a[4] = {0, 0, 0, 0};
+        if (live) {
+            if (qu == 0) a[0] = bcol != 0 ? side[((int64_t)s * nb + kk) * M + x] : ps[(int64_t)g0 * M + x];
+            auto at = [&](int j) { return j < n0 ? ps[(int64_t)(g0 + j) * M + x] : ps[(int64_t)(j - n0) * M + xn]; };
+            int j = ja;
+            for (; j + 3 < jb; j += 4) {   // independent streams: the loads of a thread do not wait for each other
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += at(j + q);
+            }
+            for (; j < jb; ++j) a[0] += at(j);
+        }
+        __syncthreads();
+        sh[qu][xl] = (a[0] + a[1]) + (a[2] + a[3]);
+        __syncthreads();
+        if (qu == 0 && live) {
+            const real acc = (sh[0][xl] + sh[1][xl]) + (sh[2][xl] + sh[3][xl]);
+            if (mode == 0) out[(o * nchan + chan) * npol + pp] = acc;
+            tot += acc;
+        }
+    }
+    if (qu == 0 && live && mode != 0) out[o * nchan + chan] = tot;
+}
+
 // ---- Bluestein (arbitrary nsample) ---------------------------------------------------------------------------
 // W_N^{nk} = b[n] b[k] conj(b[k-n]) with b[n] = exp(-i pi n^2 / N), so
 //   FFT_N(x)[k] = b[k] * ((x b) (*) conj(b))[k]

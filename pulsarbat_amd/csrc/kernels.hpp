@@ -176,7 +176,45 @@ struct ColpParams {
     int64_t ld_plane = 0;
     int64_t st_shift = 0;
     int P = 1;  // column transform split P x M (k_radix_p did the radix-P stage): a series is P blocks of M rows
+    // DET (OP_TW_INV, F = 16, P = 1): the pass stores no voltages.  Each tile leaves |z|^2 summed over its 16 columns, one
+    // float per row, in det_part[(series * groups + g) * M + tau * R + i] (row = tau + (M/R) i); a column group that holds
+    // a scrunch boundary (time index == crop_start mod det_ns) inside it leaves the columns before the boundary there and
+    // the rest in det_side[(series * (N2/det_ns) + boundary) * M + ...].  k_detect_reduce sums them per output sample.
+    real* det_part = nullptr;
+    real* det_side = nullptr;
+    int det_ns = 0;
 };
+
+#ifndef PBH_DET_PUMP
+#define PBH_DET_PUMP 2   // loads requested per tick of the detecting column pass (it has no stores to pace them with)
+#endif
+#ifndef PBH_F64
+// sum over the 16 lanes of a DPP row of 32 values per lane, transposed on the way: lane f ends with the totals of values
+// 2f and 2f + 1.  Step k halves the values a lane is responsible for (the half chosen by one bit of f) and adds the partner's
+// contribution to that half; partners: f^8 (row_ror:8), f^7 (row_half_mirror), f^2, f^1 (quad_perm).  30 DPP adds
+// instead of the 128 of an all-reduce, and the result is one 8-byte store per lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_from(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int N, int CTRL>
+__device__ __forceinline__ void treduce_step(const float* in, float* out, bool bit) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float keep = bit ? in[j + N] : in[j];
+        const float send = bit ? in[j] : in[j + N];
+        out[j] = keep + dpp_from<CTRL>(send);
+    }
+}
+__device__ __forceinline__ float2 treduce16x32(const float* a, int f) {
+    float b[16], c[8], d[4], e[2];
+    treduce_step<16, 0x128>(a, b, (f & 8) != 0);
+    treduce_step<8, 0x141>(b, c, (f & 4) != 0);
+    treduce_step<4, 0x4E>(c, d, (f & 2) != 0);
+    treduce_step<2, 0xB1>(d, e, (f & 1) != 0);
+    return make_float2(e[0], e[1]);
+}
+#endif
 
 // ---- persistent column pass with deferred, interleaved stores --------------------------------------
 // The outputs of tile i are not stored when they are ready: a burst of 32 stores per thread blocks
@@ -187,9 +225,10 @@ struct ColpParams {
 // is two tiles of registers (the one being transformed, and the out/in slots).  Out-of-range
 // descriptors (0 bytes) turn the first iteration's stores and the last iterations' loads into
 // no-ops without branches.
-template <int M, int OP, int R>
+template <int M, int OP, int R, bool DET = false>
 __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     constexpr int F = kTilePoints / M;
+    static_assert(!DET || (OP == OP_TW_INV && F == 16 && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,7 +314,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
 #pragma unroll
             for (int k = 0; k < n; ++k) {
                 if (cnt < R) {
-                    if constexpr (OP == OP_TW_INV) {
+                    if constexpr (DET) {
+                    } else if constexpr (OP == OP_TW_INV) {
                         // cropped samples: an out-of-range offset makes the hardware drop the store (no branch)
                         const uint32_t tt = tto + (uint32_t)cnt * rowstep;
                         buf_store(rdo, (tt >= c0 && tt < c1) ? voff : (int)0x80000000, cnt * stepb, out[cnt]);
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         auto hk = [&](auto st, auto q) {
             if constexpr (std::is_same<decltype(q), tick_tag>::value) {
                 __builtin_amdgcn_sched_barrier(0x38E);  // VALU / SALU / LDS may move across, global memory ops stay put
-                pump(2);
+                pump(DET ? PBH_DET_PUMP : 2);
                 __builtin_amdgcn_sched_barrier(0x38E);
             }
         };
@@ -312,6 +352,28 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         // tables of the next tile: after every request above, before nothing that has to wait for them
         const int gn = more ? group_of(tn) : g;
         if (more) load_tables(gn * F + f, block_of(tn), zbh, zbl, zsh, zsl);
+#ifndef PBH_F64
+        if constexpr (DET) {
+            float pw[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) pw[i] = v[i].x * v[i].x + v[i].y * v[i].y;
+            const int bmod = (int)(p.crop_start % p.det_ns), bcol = bmod & (F - 1);
+            const bool split = bcol != 0 && (g * F) % p.det_ns == bmod - bcol;   // tile-uniform
+            const int64_t at = (int64_t)tau * R + 2 * f;
+            float2* dst = reinterpret_cast<float2*>(p.det_part + ((int64_t)series_of(t) * ngrp + g) * M + at);
+            if (split) {
+                float lo[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    lo[i] = f < bcol ? pw[i] : 0.0f;
+                    pw[i] -= lo[i];
+                }
+                *dst = treduce16x32(lo, f);
+                dst = reinterpret_cast<float2*>(p.det_side + ((int64_t)series_of(t) * (p.N2 / p.det_ns) + (g * F) / p.det_ns) * M + at);
+            }
+            *dst = treduce16x32(pw, f);
+        } else
+#endif
         if constexpr (OP == OP_TW_INV) {
 #pragma unroll
             for (int i = 0; i < R; ++i) out[i] = v[i];
@@ -334,6 +396,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         g = gn;
     }
     // drain: the last tile's outputs
+    if constexpr (DET) return;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         if constexpr (OP == OP_TW_INV) {

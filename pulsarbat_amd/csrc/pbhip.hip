@@ -231,6 +231,8 @@ struct pbh_plan {
 
     cf* work = nullptr;      // planar workspace, S * N
     cf* work2 = nullptr;     // second planar workspace: the middle passes of the power-of-two planar pipeline ping-pong (oop_ok)
+    real* det_part = nullptr;  // detect tail fused into the inverse column pass: per-tile power sums (ColpParams::det_part),
+    size_t det_bytes = 0;      // S * N / 16 floats + S * N1 * (N2 / nscrunch) for the groups with a scrunch boundary
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
     float* chirp_phase = nullptr;  // same order, revolutions: what k_rowp reads (generated chirps only)
     bool has_phase = false;
@@ -382,6 +384,17 @@ static int colp_mode() {
     static int m = [] { const char* e = getenv("PBH_COLP"); return e ? atoi(e) : 2; }();
     return m;
 }
+#ifndef PBH_F64
+// the inverse column pass that detects instead of storing (N1 = 1024: 16-column tiles)
+static int launch_colq_det(ColpParams prm, hipStream_t st) {
+    constexpr int M = 1024, F = kTilePoints / M;
+    prm.order = 0;
+    int64_t tiles = (int64_t)prm.S * (prm.N2 / F);
+    if (tiles > row_grid()) tiles = row_grid();
+    if (colp_mode() < 2) prm.counter = nullptr;
+    return launch_tile_kernel(k_colq<M, OP_TW_INV, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+}
+#endif
 template <int OP>
 static int launch_colq(int M, ColpParams prm, hipStream_t st) {
     const int F = kTilePoints / M;
@@ -767,6 +780,26 @@ static cf* ensure_work2(pbh_plan* p) {
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
 
+// Detection inside the inverse column pass (k_colq<.., DET> + k_detect_reduce): for |z|^2 and Stokes I, whose sums need one
+// series at a time.  PBH_DETECT_COLQ=0 restores the separate read pass over the dedispersed voltages (k_detect_planar).
+static bool detect_in_colq() {
+    static const bool on = [] { const char* e = getenv("PBH_DETECT_COLQ"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+static real* ensure_det_part(pbh_plan* p, size_t bytes) {
+    if (p->det_bytes < bytes) {
+        if (p->det_part) (void)hipFree(p->det_part);
+        p->det_part = nullptr;
+        p->det_bytes = 0;
+        void* q = nullptr;
+        if (dev_alloc(p, &q, bytes) == PBH_OK) {
+            p->det_part = (real*)q;
+            p->det_bytes = bytes;
+        } else (void)hipGetLastError();
+    }
+    return p->det_part;
+}
+
 // columns per k_colmix tile: a power of two, as many as keep L rows within the 64-KiB tile (short transforms get wide
 // tiles: a 25-point stage works on 25 x 256 points per tile); whole 128-byte lines up to L = 512, 64-byte pieces beyond
 static int mix_wlog2(int L, int N2) {
@@ -1100,6 +1133,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                           (colp_mode() != 0 && Q >= 64 && Q <= kTilePoints && N2 % (kTilePoints / Q) == 0 && N < (1LL << 31));
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);  // two tile counters behind the table
         ColpParams cp1{work, N, S, N2, tw, p->tw16k, 0, N, 0, ctr};
+        bool det_done = false; // the detect tail ran inside the inverse column pass
         cf* workB = nullptr;   // ping-pong schedule (oop_mode): column pass A -> B, row pass B -> A, column pass A -> B
 #ifndef PBH_F64
         if (oop_mode() && !depth_mode() && P == 1 && colp && !in_sm && !out_sm && !fuse_radix && p->has_phase && row_phase_enabled() &&
@@ -1201,6 +1235,33 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             cp3.crop_start = 0;
             cp3.crop_stop = N;
         }
+#ifndef PBH_F64
+        // Detect tail inside this pass: the dedispersed voltages are never stored (saves their write and the read of
+        // k_detect_planar: 2 x 8 of the 60 bytes per sample of configs[4]).
+        if (tail.out && tail.mode <= PBH_DETECT_STOKES_I && detect_in_colq() && colp && P == 1 && Q == 1024 && PBH_R == 32 && !workB &&
+            N2 % tail.nscrunch == 0 && tail.nscrunch % 16 == 0 && (stop - start) / tail.nscrunch > 0) {
+            const int ns = tail.nscrunch, nchan = p->nchan, npol = p->npol, mode = tail.mode;
+            const size_t npart = (size_t)S * (size_t)(N2 / 16) * (size_t)Q, nside = (size_t)S * (size_t)(N2 / ns) * (size_t)Q;
+            real* part = ensure_det_part(p, (npart + nside) * sizeof(real));
+            if (part) {
+                cp3.det_part = part;
+                cp3.det_side = part + npart;
+                cp3.det_ns = ns;
+                const int64_t nout = (stop - start) / ns;
+                real* dout = tail.out;
+                const ColpParams cpd = cp3;
+                steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colq_det(cpd, st); }});
+                steps.push_back({"k_detect_reduce", [=](hipStream_t st) {
+                    hipLaunchKernelGGL(k_detect_reduce, dim3((unsigned)((Q + 63) / 64), (unsigned)(N2 / ns), (unsigned)nchan), dim3(256), 0, st,
+                                       (const real*)cpd.det_part, (const real*)cpd.det_side, dout, N2, Q, (int)PBH_R, ns, start, nout, nchan, npol, mode);
+                    HIPCHECK(hipGetLastError());
+                    return (int)PBH_OK;
+                }});
+                det_done = true;
+            }
+        }
+        if (!det_done)
+#endif
         steps.push_back({"k_col_inv", [=](hipStream_t st) {
             return colp ? launch_colq<OP_TW_INV>(Q, cp3, st) : launch_col<OP_TW_INV>(N1, c3, st);
         }});
@@ -1221,7 +1282,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 }});
             }
         }
-        if (tail.out) {
+        if (det_done) {
+        } else if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
             steps.push_back({"k_detect_planar", [=](hipStream_t st) {
@@ -1976,7 +2038,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->sub) pbh_plan_destroy(p->sub);
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) (void)hipFree(p->cf_in);
-    void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
+    void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->det_part, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
                     p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm, p->mixR.wl, p->mixR.perm};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);

@@ -17,7 +17,9 @@ def step(kname):
 # per kernel name: mean over dispatches; a step's traffic is the SUM over the kernels it launches
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges a call's files into what earlier calls left in the same directory: the newest file of a pass is the run
+    files = sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if step(r["Kernel_Name"]):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
