@@ -127,6 +127,24 @@ static bool is_7smooth(int64_t n) {
     for (int f : {2, 3, 5, 7}) while (n % f == 0) n /= f;
     return n == 1;
 }
+static bool split_levels(int64_t n1, int64_t* qout) {
+    int64_t q = 0;
+    static const int64_t forced = [] { const char* e = getenv("PBH_MIX_Q"); return e ? atoll(e) : 0LL; }();   // (timing runs)
+    if (n1 <= kMixMaxLen) q = n1;
+    else if (forced > 1 && n1 % forced == 0 && forced <= kMixMaxLen && n1 / forced <= kMixMaxLen) q = forced;
+    else {
+        // two levels: both factors within 512 rows if there is such a split (tiles of whole 128-byte lines in both passes;
+        // beyond 512 rows a tile holds 64-byte pieces), the larger one as the Q-point pass.  (Round 3 measured the most
+        // balanced split instead on 16 lengths: 0.86-1.09x, median 0.96x -- profiles/r03_mix_split.txt; what was slow about
+        // the unbalanced ones was the tile kernel on 3 and 5 rows: mix_radix_p.)
+        for (int64_t d = 512; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= 512) q = d;
+        for (int64_t d = kMixMaxLen; d >= 2 && !q; --d)
+            if (n1 % d == 0 && n1 / d <= kMixMaxLen) q = d;
+    }
+    *qout = q;
+    return q != 0;
+}
 static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     // PBH_MIXED: 0 = off, 1 = only lengths whose N1 fits one column pass (P = 1: 5 passes, 1.5x the rate of the padded
     // convolution), 2 (default) = two-level lengths as well (7 passes: 1.06-1.14x the convolution plan, half its memory)
@@ -139,16 +157,7 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
     const int64_t n1 = n >> k;
     if (n1 < 2) return false;
     int64_t q = 0;
-    if (n1 <= kMixMaxLen) q = n1;
-    else {
-        // two levels: both factors within 512 rows if there is such a split (tiles of whole 128-byte lines in both passes;
-        // beyond 512 rows a tile holds 64-byte pieces), the larger one as the Q-point pass
-        for (int64_t d = 512; d >= 2 && !q; --d)
-            if (n1 % d == 0 && n1 / d <= 512) q = d;
-        for (int64_t d = kMixMaxLen; d >= 2 && !q; --d)
-            if (n1 % d == 0 && n1 / d <= kMixMaxLen) q = d;
-    }
-    if (!q) return false;
+    if (!split_levels(n1, &q)) return false;
     if (mode < 2 && n1 / q > 1) return false;
     *N2 = 1 << k;
     *N1 = (int)n1;
@@ -160,18 +169,6 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
 // (k_rowmix): N2 = 2^k * f, f odd, at most 1024 points, as long as possible such that N1 = N / N2 still splits into column
 // levels of at most 1024 rows.  The column passes take pieces of up to 512 elements of a row, the last one of a row short
 // (rows start at multiples of 2^k elements: 16 to 128 bytes).  PBH_ROWMIX=0: off.
-static bool split_levels(int64_t n1, int64_t* qout) {
-    int64_t q = 0;
-    if (n1 <= kMixMaxLen) q = n1;
-    else {
-        for (int64_t d = 512; d >= 2 && !q; --d)
-            if (n1 % d == 0 && n1 / d <= 512) q = d;
-        for (int64_t d = kMixMaxLen; d >= 2 && !q; --d)
-            if (n1 % d == 0 && n1 / d <= kMixMaxLen) q = d;
-    }
-    *qout = q;
-    return q != 0;
-}
 static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
     static const bool on = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) != 0 : true; }();
     static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 2; }();
@@ -837,6 +834,15 @@ static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st, bool fwd_o
                     : launch_tile_kernel(k_rowmix<false>, r, tiles, 512, st, (int)lds);
 }
 
+// The P-point stage of a two-level 7-smooth plan with a SHORT P runs the elementwise k_radix_p (P samples one chunk apart per
+// thread, fully coalesced) instead of k_colmix: a 3-row tile of at most 512 columns leaves the tile kernel 1536 points for 512
+// threads (9 953 280 = 2^13 * 3 * 405, 16 series: 1.22 ms per pass as a tile, 0.75 for 5 rows; profiles/r03_mix_split.txt).
+// PBH_MIX_RADIXP=0: the tile kernel for every P.
+static bool mix_radix_p(int P) {
+    static const bool on = [] { const char* e = getenv("PBH_MIX_RADIXP"); return e ? atoi(e) != 0 : true; }();
+    return on && (P == 2 || P == 3 || P == 4 || P == 5 || P == 7 || P == 8);
+}
+
 // k_colmix parameters of a mixed plan's two column roles (mixed_kernels.hpp): A = the P-point stage over rows one chunk
 // N / P apart, B = the Q-point pass inside each of the P row blocks.  ld / st: planar arrays (series pitch ldp / stpl);
 // only element (time) indices in [k0, k1) are stored, at index - shift.
@@ -1021,9 +1027,17 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);   // tile counters: 2 = rows, 3..6 = the column passes
         const pbh_plan* cp = p;
         if (P > 1) {
-            MixParams a = role_a(src, splane, work, N, 0, N, 0);
-            a.counter = ctr + 3;
-            steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_colmix<-1>(a, st); }});
+            if (mix_radix_p(P)) {
+                const cf* rsrc = src;
+                const int64_t rplane = splane;
+                steps.push_back({"k_radix_fwd", [=](hipStream_t st) {
+                    return launch_radix<-1>(P, rsrc, rplane, work, N, S, N, N2, N1, 0, N, st);
+                }});
+            } else {
+                MixParams a = role_a(src, splane, work, N, 0, N, 0);
+                a.counter = ctr + 3;
+                steps.push_back({"k_radix_fwd", [=](hipStream_t st) { return launch_colmix<-1>(a, st); }});
+            }
             src = work;
             splane = N;
         }
@@ -1054,9 +1068,17 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colmix<+1>(b, st); }});
         }
         if (P > 1) {
-            MixParams a = role_a(work, N, dst, dplane, start, stop, dshift);
-            a.counter = ctr + 6;
-            steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
+            if (mix_radix_p(P)) {
+                // (k_radix_p stores time t at t - keep0: cropped when it writes the caller's series-major array, whole in place)
+                const int64_t k0 = direct_out ? start : 0, k1 = direct_out ? stop : N;
+                steps.push_back({"k_radix_inv", [=](hipStream_t st) {
+                    return launch_radix<+1>(P, work, N, dst, dplane, S, N, N2, N1, k0, k1, st);
+                }});
+            } else {
+                MixParams a = role_a(work, N, dst, dplane, start, stop, dshift);
+                a.counter = ctr + 6;
+                steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
+            }
         }
         if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
@@ -3137,9 +3159,13 @@ static int native_forward(pbh_plan* p, const cf* din, int il, hipStream_t st) {
         unsigned* ctr = reinterpret_cast<unsigned*>(p->tw16k + kTwTable);
         HIPCHECK(hipMemsetAsync(ctr, 0, kCounterBytes, st));
         if (P > 1) {
-            MixParams a = mix_role_a(p, src, n, work, n, 0, n, 0);
-            a.counter = ctr + 3;
-            PBHCHECK(launch_colmix<-1>(a, st));
+            if (mix_radix_p(P)) {
+                PBHCHECK(launch_radix<-1>(P, src, n, work, n, S, n, N2, N1, 0, n, st));
+            } else {
+                MixParams a = mix_role_a(p, src, n, work, n, 0, n, 0);
+                a.counter = ctr + 3;
+                PBHCHECK(launch_colmix<-1>(a, st));
+            }
             src = work;
         }
         MixParams b = mix_role_b(p, src, n, work, n, 0, n, 0);

@@ -1057,8 +1057,8 @@ def mixed_all(monkeypatch):
     import subprocess
     import sys
 
-    def run(code):
-        env = dict(os.environ, PBH_MIXED="2")
+    def run(code, **more):
+        env = dict(os.environ, PBH_MIXED="2", **more)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -1067,8 +1067,9 @@ def mixed_all(monkeypatch):
 
 
 def test_7smooth_two_level_lengths(mixed_all):
-    """N1 = P * Q beyond one column tile (P > 1): both column roles of k_colmix, complex64 and complex128."""
-    out = mixed_all("""
+    """N1 = P * Q beyond one column tile (P > 1): both column roles of k_colmix, complex64 and complex128; the P-point stage of
+    the first two lengths (P = 3, 5) runs the elementwise k_radix_p by default and the tile kernel with PBH_MIX_RADIXP=0."""
+    code = """
 import numpy as np, sys
 sys.path.insert(0, "tests")
 import test_gpu_parity as t
@@ -1081,8 +1082,9 @@ for n, n1, n2 in [(64800, 2025, 32), (400000, 3125, 128), (1000000, 15625, 64)]:
             t.check((n,) + tail, 3.0, 1e6, 1e9, seed=n % 97, device=device)
 t.check128((400000, 2, 2), 3.0)
 print("two-level ok")
-""")
-    assert "two-level ok" in out
+"""
+    assert "two-level ok" in mixed_all(code)
+    assert "two-level ok" in mixed_all(code, PBH_MIX_RADIXP="0")
 
 
 @pytest.mark.parametrize("n,n1,n2", SMOOTH)
