@@ -607,16 +607,19 @@ def test_repeatable_bit_for_bit(dtype, shape, dm):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,nscrunch,dm,ref", [("I", 1024, 56.77, None), ("I", 64, 56.77, None), ("intensity", 16384, 30.0, None),
                                                   ("I", 1024, 20.0, "top"), ("intensity", 256, 100.0, "bottom"),
-                                                  ("I", 4096, 3.0, None)])
+                                                  ("I", 4096, 3.0, None), ("linear", 1024, 56.77, None),
+                                                  ("circular", 256, 20.0, "top"), ("linear", 16384, 101.0, None)])
 def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
     """N = 2^24 (1024-row column tiles): |z|^2 and Stokes I are summed inside the inverse column pass and the dedispersed
-    voltages are never stored (k_colq<.., DET> + k_detect_reduce).  Same numbers as detecting the stored voltages, for
+    voltages are never stored (k_colq<.., DET> + k_detect_reduce; the four-parameter modes keep the read pass over the stored
+    voltages, k_detect_planar, and are checked here at the same size).  Same numbers as detecting the stored voltages, for
     crop starts that are and are not multiples of the 16-column tile width (ref_freq at the band edges: start or stop at
     the end of the block), scrunch factors from one tile-row fraction to a whole row, sample-major and series-major input."""
     n, nchan, npol, sr, fc = 1 << 24, 2, 2, 50e6, 1.4e9
     rng = np.random.default_rng(61)
     x = rng.standard_normal((n, nchan, npol, 2), dtype=np.float32).view(np.complex64)[..., 0]
     x *= (1 + np.arange(nchan * npol, dtype=np.float32).reshape(nchan, npol))   # every series its own power
+    x[..., 1] += np.complex64(0.5 + 0.3j) * x[..., 0]                           # ... and the pols correlated: U, V != 0
     z = make_signal(x, sr, fc).to_device()
     rf = None if ref is None else (fc + sr * nchan / 2 if ref == "top" else fc - sr * nchan / 2) * u.Hz
     y = pb.coherent_dedispersion(z, pb.DM(dm), ref_freq=rf)
@@ -624,14 +627,21 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
     pw = (yv.real.astype(np.float64) ** 2 + yv.imag.astype(np.float64) ** 2)
     nout = len(pw) // nscrunch
     want = pw[:nout * nscrunch].reshape(nout, nscrunch, nchan, npol).sum(1)
+    scale = want.sum(-1, keepdims=True)   # Stokes I: what Q, U, V (which may vanish) are compared against
     if mode == "I":
         want = want.sum(-1)
+        scale = want
+    elif mode != "intensity":   # all four parameters from the pol pair (core.py:930-966)
+        ab = (np.conj(yv[..., 0].astype(np.complex128)) * yv[..., 1])[:nout * nscrunch].reshape(nout, nscrunch, nchan).sum(1)
+        d = want[..., 0] - want[..., 1]
+        quv = (d, 2 * ab.real, 2 * ab.imag) if mode == "linear" else (2 * ab.real, 2 * ab.imag, d)
+        want = np.stack((want.sum(-1),) + quv, axis=-1)
     got, start = pb.dedisperse_detect(z, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=nscrunch)
     got = np.asarray(got)
     assert got.shape == want.shape and got.dtype == np.float32
     if ref is None:
         assert start % 16 != 0, "pick a DM whose crop start is not tile-aligned"
-    rel = np.abs(got - want) / want
+    rel = np.abs(got - want) / scale
     assert rel.max() < 2e-5, f"start {start}: max relative difference {rel.max():.2e}"
     zs = type(z).like(z, z.data.to_series_major())
     got_s, start_s = pb.dedisperse_detect(zs, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=nscrunch)

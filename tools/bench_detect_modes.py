@@ -1,0 +1,35 @@
+"""dedisperse + detect + 1024x scrunch at configs[4]'s per-GPU geometry for every detect mode, with the detection inside the
+inverse column pass (default) and as a read pass of its own (PBH_DETECT_COLQ=0), a child process per setting."""
+import json, os, subprocess, sys, time
+
+CHILD = r'''
+import sys, time, json
+sys.path.insert(0, ".")
+import numpy as np, torch
+from pulsarbat_amd import _hip
+from pulsarbat_amd.device import DeviceArray
+sys.path.insert(0, "tools")
+from bench_configs import crop
+n, nchan_tot, nchan, npol, dm, band, center = 1 << 24, 64, 8, 2, 1000.0, 400e6, 1.4e9
+sr = band / nchan_tot
+start, stop = crop(dm, n, band, center, sr)
+freqs = (center + sr * (np.arange(nchan_tot) + 0.5 - nchan_tot / 2))[:nchan]
+x = DeviceArray(torch.view_as_complex(torch.randn((n, nchan, npol, 2), device="cuda") * 0.7071))
+plan = _hip.Plan(n, nchan, npol, start, stop)
+plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, center)
+res = {}
+for mode in ("intensity", "I", "linear", "circular"):
+    for _ in range(3):
+        out = plan.dedisperse_detect(x, nscrunch=1024, mode=mode)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        out = plan.dedisperse_detect(x, nscrunch=1024, mode=mode)
+    torch.cuda.synchronize()
+    res[mode] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+print(json.dumps(res))
+'''
+for flag in ("1", "0"):
+    env = dict(os.environ, PBH_DETECT_COLQ=flag)
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    print(f"PBH_DETECT_COLQ={flag}: ms per step {line[-1] if line else r.stderr[-600:]}", flush=True)
