@@ -646,6 +646,11 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
     zs = type(z).like(z, z.data.to_series_major())
     got_s, start_s = pb.dedisperse_detect(zs, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=nscrunch)
     assert start_s == start and np.array_equal(np.asarray(got_s), got)
+    if mode == "I" and nscrunch == 1024 and ref is None:
+        # a chirp given by the caller (complex64 rows, k_row instead of the phase-row kernel in front of the detecting pass)
+        c = pb.DM(dm).chirp_from_signal(z)   # device-resident, (n, nchan, 1)
+        got_c, start_c = pb.dedisperse_detect(z, pb.DM(dm), chirp=c, mode=mode, nscrunch=nscrunch)
+        assert start_c == start and np.allclose(np.asarray(got_c), got, rtol=1e-5)
 
 
 @pytest.mark.gpu
