@@ -176,8 +176,8 @@ struct ColpParams {
     int64_t ld_plane = 0;
     int64_t st_shift = 0;
     int P = 1;  // column transform split P x M (k_radix_p did the radix-P stage): a series is P blocks of M rows
-    // DET (OP_TW_INV, F = 16, P = 1): the pass stores no voltages.  Each tile leaves |z|^2 summed over its 16 columns, one
-    // float per row, in det_part[(series * groups + g) * M + tau * R + i] (row = tau + (M/R) i); a column group that holds
+    // DET (OP_TW_INV, F = 16, 32 or 64 columns, P = 1): the pass stores no voltages.  Each tile leaves |z|^2 summed over every
+    // 16 of its columns, one float per row, in det_part[(series * N2/16 + g16) * M + tau * R + i] (row = tau + (M/R) i); a column group that holds
     // a scrunch boundary (time index == crop_start mod det_ns) inside it leaves the columns before the boundary there and
     // the rest in det_side[(series * (N2/det_ns) + boundary) * M + ...].  k_detect_reduce sums them per output sample.
     real* det_part = nullptr;
@@ -228,7 +228,7 @@ __device__ __forceinline__ float2 treduce16x32(const float* a, int f) {
 template <int M, int OP, int R, bool DET = false>
 __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     constexpr int F = kTilePoints / M;
-    static_assert(!DET || (OP == OP_TW_INV && F == 16 && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
+    static_assert(!DET || (OP == OP_TW_INV && F % 16 == 0 && F <= 64 && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,21 +357,28 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
             float pw[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) pw[i] = v[i].x * v[i].x + v[i].y * v[i].y;
-            const int bmod = (int)(p.crop_start % p.det_ns), bcol = bmod & (F - 1);
-            const bool split = bcol != 0 && (g * F) % p.det_ns == bmod - bcol;   // tile-uniform
-            const int64_t at = (int64_t)tau * R + 2 * f;
-            float2* dst = reinterpret_cast<float2*>(p.det_part + ((int64_t)series_of(t) * ngrp + g) * M + at);
+            // a tile is F / 16 groups of 16 columns, one per DPP row of the wave; the partial sums are per group
+            const int fl = f & 15, c16 = g * F + (f & ~15);      // lane's column within its group; the group's first column
+            const int bmod = (int)(p.crop_start % p.det_ns), bcol = bmod & 15;
+            const int first = (g * F) % p.det_ns;                // tile-uniform: does one of this tile's groups hold a boundary?
+            const bool split = bcol != 0 && first <= bmod - bcol && bmod - bcol < first + F;
+            const int64_t at = (int64_t)tau * R + 2 * fl;
+            float2* dst = reinterpret_cast<float2*>(p.det_part + ((int64_t)series_of(t) * (p.N2 / 16) + c16 / 16) * M + at);
             if (split) {
+                const bool mine = c16 % p.det_ns == bmod - bcol;   // this lane's group is the one
                 float lo[R];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    lo[i] = f < bcol ? pw[i] : 0.0f;
+                    lo[i] = (mine && fl >= bcol) ? 0.0f : pw[i];
                     pw[i] -= lo[i];
                 }
-                *dst = treduce16x32(lo, f);
-                dst = reinterpret_cast<float2*>(p.det_side + ((int64_t)series_of(t) * (p.N2 / p.det_ns) + (g * F) / p.det_ns) * M + at);
+                *dst = treduce16x32(lo, fl);
+                const float2 hi = treduce16x32(pw, fl);
+                if (mine)
+                    *reinterpret_cast<float2*>(p.det_side + ((int64_t)series_of(t) * (p.N2 / p.det_ns) + c16 / p.det_ns) * M + at) = hi;
+            } else {
+                *dst = treduce16x32(pw, fl);
             }
-            *dst = treduce16x32(pw, f);
         } else
 #endif
         if constexpr (OP == OP_TW_INV) {

@@ -654,6 +654,27 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log2n,mode,nscrunch,dm", [(22, "I", 1024, 30.0), (22, "intensity", 64, 5.0), (23, "I", 256, 56.77),
+                                                    (23, "intensity", 16384, 10.0), (22, "I", 4096, 0.7)])
+def test_detect_inside_the_column_pass_wider_tiles(log2n, mode, nscrunch, dm):
+    """The same for 2^22 and 2^23 samples (256- and 512-row column tiles of 64 and 32 columns: four and two 16-column groups per
+    tile, the scrunch boundary inside any of them), against the oracle."""
+    n, nchan, npol, sr, fc = 1 << log2n, 3, 2, 10e6, 1.2e9
+    x = orc.synthetic_block((n, nchan, npol), 71)
+    z = make_signal(x, sr, fc)
+    got, start = pb.dedisperse_detect(z.to_device(), pb.DM(dm), mode=mode, nscrunch=nscrunch)
+    yr, s0, _ = orc.coherent_dedispersion(x, dm, sr, fc)
+    want = orc.scrunch(orc.to_intensity(yr) if mode == "intensity" else orc.to_stokes(yr, "linear")[:, :, 0], nscrunch)
+    got = np.asarray(got)
+    assert start == s0 and got.shape == want.shape
+    assert np.abs(got - want).max() < 3e-5 * np.abs(want).max()
+    zs = z.to_device()
+    zs = type(zs).like(zs, zs.data.to_series_major())
+    got_s, _ = pb.dedisperse_detect(zs, pb.DM(dm), mode=mode, nscrunch=nscrunch)
+    assert np.array_equal(np.asarray(got_s), got)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,nscrunch", [("I", 64), ("linear", 128), ("intensity", 64), ("I", 16)])
 def test_series_major_dedisperse_detect(mode, nscrunch):
     """dedisperse_detect on a series-major device array: same numbers as on the contiguous array."""

@@ -1,5 +1,5 @@
 """Randomised check of the detection inside the inverse column pass (k_colq<1024, INV, DET> + k_detect_reduce; test
-infrastructure, about a second per case on the GPU box): blocks of 2^24 samples with random channel / polarisation counts,
+infrastructure, a few tens of ms per case on the GPU box): blocks of 2^22, 2^23 and 2^24 samples with random channel / polarisation counts,
 DMs (crop starts of every residue mod 16, crops from a few rows to most of the block), reference frequencies, scrunch
 factors 64 ... 16384 and both fusable modes, sample-major and series-major input, against the scrunched power of the
 voltages the ordinary call returns (float64 sums on the host).
@@ -15,10 +15,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-n = 1 << 24
 cases = bad = 0
 residues = set()
 while time.time() < t_end:
+    n = 1 << int(rng.choice([22, 23, 24]))   # 256-, 512- and 1024-row column tiles (64, 32, 16 columns)
     nchan = int(rng.integers(1, 4))
     npol = int(rng.choice([1, 2]))
     sr = float(rng.choice([1e6, 6.25e6, 50e6]))

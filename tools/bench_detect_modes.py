@@ -10,7 +10,7 @@ from pulsarbat_amd import _hip
 from pulsarbat_amd.device import DeviceArray
 sys.path.insert(0, "tools")
 from bench_configs import crop
-n, nchan_tot, nchan, npol, dm, band, center = 1 << 24, 64, 8, 2, 1000.0, 400e6, 1.4e9
+n, nchan_tot, nchan, npol, dm, band, center = 1 << LOG2N, NCHAN_TOT, 8, 2, DMV, 400e6, 1.4e9
 sr = band / nchan_tot
 start, stop = crop(dm, n, band, center, sr)
 freqs = (center + sr * (np.arange(nchan_tot) + 0.5 - nchan_tot / 2))[:nchan]
@@ -28,6 +28,12 @@ for mode in ("intensity", "I", "linear", "circular"):
     res[mode] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
 print(json.dumps(res))
 '''
+# usage: python tools/bench_detect_modes.py [log2n=24] [nchan_total=64] [dm=1000]   (22 8 56.77: configs[3]'s chunk geometry)
+log2n = sys.argv[1] if len(sys.argv) > 1 else "24"
+nchan_tot = sys.argv[2] if len(sys.argv) > 2 else "64"
+dmv = sys.argv[3] if len(sys.argv) > 3 else "1000.0"
+CHILD = CHILD.replace("LOG2N", log2n).replace("NCHAN_TOT", nchan_tot).replace("DMV", dmv)
+print(f"2^{log2n} samples x 8 of {nchan_tot} channels x 2 pol, DM {dmv}, 1024x scrunch")
 for flag in ("1", "0"):
     env = dict(os.environ, PBH_DETECT_COLQ=flag)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
