@@ -621,7 +621,11 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const cf* __restrict__ 
 }
 
 // planar [s][t] -> (stop-start, S); the tail tile is handled by the generic kernel
-template <int S, bool PITCHED = false, bool SHIFTED = false>
+// DET >= 0 (float32 build): the pass DETECTS instead -- the two series a lane holds for one time sample are the two
+// polarisations of a channel (series = chan * npol + pol), so what leaves is float32 at full time resolution,
+//   0: |z|^2 per element (rows of S floats);  1: Stokes I (rows of S/2);  2 / 3: I, Q, U, V linear / circular (rows of 2 S)
+// -- pulsarbat's to_intensity / to_stokes (core.py:766-774, 930-966) of voltages that are never stored.
+template <int S, bool PITCHED = false, bool SHIFTED = false, int DET = -1>
 __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ in, cf* __restrict__ out,
                                                          int64_t start, int64_t plane, int64_t opitch,
                                                          const int64_t* __restrict__ dly = nullptr) {
@@ -668,6 +672,20 @@ __global__ __launch_bounds__(256) void k_reinterleave_p2(const cf* __restrict__ 
             x = lds[slot(s, n)];
             y = lds[slot(s + 1, n)];
         }
+        if constexpr (DET >= 0) {
+            real* ro = reinterpret_cast<real*>(out);
+            const int64_t r = t0 - start + n;
+            const real aa = x.x * x.x + x.y * x.y, bb = y.x * y.x + y.y * y.y;
+            if constexpr (DET == 0) {
+                *reinterpret_cast<float2*>(ro + r * S + s) = make_float2(aa, bb);
+            } else if constexpr (DET == 1) {
+                ro[r * (S / 2) + s / 2] = aa + bb;
+            } else {
+                const real re2 = 2 * (x.x * y.x + x.y * y.y), im2 = 2 * (x.x * y.y - x.y * y.x);   // 2 conj(a) b
+                *reinterpret_cast<float4*>(ro + (r * (S / 2) + s / 2) * 4) =
+                    DET == 2 ? make_float4(aa + bb, aa - bb, re2, im2) : make_float4(aa + bb, re2, im2, aa - bb);
+            }
+        } else
         if constexpr (PITCHED)   // rows are a slice of a wider array (S >= 2, opitch and the base even: 16-byte vectors)
             *reinterpret_cast<float4*>(out + (t0 - start + n) * opitch + s) = make_float4(x.x, x.y, y.x, y.y);
         else

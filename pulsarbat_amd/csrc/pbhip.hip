@@ -678,6 +678,50 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
     return PBH_OK;
 }
 
+// The final layout pass as a DETECTING pass at full time resolution (k_reinterleave_p2<.., DET>): float32 to_intensity /
+// to_stokes of the cropped samples straight from the planar workspace.  Whole tiles through the tile kernel, the last rows
+// through k_detect_planar (one output per wavefront: fine for fewer rows than a tile).
+static bool reint_detect_ok(int S, int npol, int mode) {
+#ifdef PBH_F64
+    (void)S; (void)npol; (void)mode;
+    return false;
+#else
+    static const bool on = [] { const char* e = getenv("PBH_DETECT_REINT"); return e ? atoi(e) != 0 : true; }();
+    if (!on || (S & (S - 1)) != 0 || S < 2 || S > 128) return false;
+    return mode == PBH_DETECT_INTENSITY || npol == 2;
+#endif
+}
+static int launch_reint_detect(const cf* work, real* out, int64_t start, int64_t stop, int S, int nchan, int npol, int mode, int64_t plane,
+                               hipStream_t st) {
+    if (stop <= start) return PBH_OK;
+#ifndef PBH_F64
+    const int TN = tr_rows(S);
+    const int64_t full = (stop - start) / TN;
+    if (full > 0) {
+        cf* o = reinterpret_cast<cf*>(out);
+        switch (S) {
+#define Y(s, m) hipLaunchKernelGGL((k_reinterleave_p2<s, false, false, m>), dim3((unsigned)full), dim3(256), 0, st, work, o, start, plane, (int64_t)s, (const int64_t*)nullptr)
+#define X(s) case s: if (mode == 0) Y(s, 0); else if (mode == 1) Y(s, 1); else if (mode == 2) Y(s, 2); else Y(s, 3); break;
+            X(2) X(4) X(8) X(16) X(32) X(64) X(128)
+#undef X
+#undef Y
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    const int64_t done = full * TN, rest = stop - start - done;
+    if (rest > 0) {
+        const int oe = mode == 0 ? npol : (mode == 1 ? 1 : 4);
+        hipLaunchKernelGGL(k_detect_planar, dim3((unsigned)((rest + 3) / 4), (unsigned)nchan), dim3(256), 0, st, work,
+                           out + done * nchan * oe, plane, start + done, rest, nchan, npol, mode, 1);
+        HIPCHECK(hipGetLastError());
+    }
+    return PBH_OK;
+#else
+    (void)work; (void)out; (void)S; (void)nchan; (void)npol; (void)mode; (void)plane; (void)st;
+    return fail(PBH_ERR_UNSUPPORTED, "detecting layout pass: float32 build only");
+#endif
+}
+
 // Layout passes with the radix-P stage folded in (float32, 2 <= S <= 128 a power of two, tiles of >= 16 samples).
 static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
     static const bool on = [] { const char* e = getenv("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
@@ -780,7 +824,7 @@ static cf* ensure_work2(pbh_plan* p) {
 }
 
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
-static bool can_fuse_detect(const pbh_plan* p, int nscrunch);
+static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode);
 
 // Detection inside the inverse column pass (k_colq<.., DET> + k_detect_reduce): for |z|^2 and Stokes I, whose sums need one
 // series at a time.  PBH_DETECT_COLQ=0 restores the separate read pass over the dedispersed voltages (k_detect_planar).
@@ -1310,6 +1354,12 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             }
         }
         if (det_done) {
+        } else if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode)) {
+            const int nchan = p->nchan, npol = p->npol, mode = tail.mode;
+            real* dout = tail.out;
+            steps.push_back({"k_reint_detect", [=](hipStream_t st) {
+                return launch_reint_detect(wlast, dout, start, stop, S, nchan, npol, mode, N, st);
+            }});
         } else if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
@@ -1365,8 +1415,11 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     return steps;
 }
 
-static bool can_fuse_detect(const pbh_plan* p, int nscrunch) {
-    return p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && nscrunch % 64 == 0 && p->nchan <= 65535;
+static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
+    if (!(p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && p->nchan <= 65535)) return false;
+    if (nscrunch % 64 == 0) return true;
+    // full time resolution: the power-of-two planar pipeline's last layout pass detects (launch_reint_detect)
+    return nscrunch == 1 && !p->mixed && !p->bsL && is_pow2(p->N) && reint_detect_ok(p->S, p->npol, mode);
 }
 
 static int run_steps(std::vector<Step>& steps, hipStream_t st) {
@@ -2967,7 +3020,7 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
     const cf* din;
     void* dout;
     PBHCHECK(resolve_io(p, in_c64, out_f32, out_bytes, in_loc, out_loc, &din, &dout));
-    if (nout > 0 && can_fuse_detect(p, nscrunch)) {
+    if (nout > 0 && can_fuse_detect(p, nscrunch, mode)) {
         DetectTail tail;
         tail.out = (real*)dout;
         tail.mode = mode;

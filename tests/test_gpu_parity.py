@@ -654,6 +654,28 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,mode", [((1 << 18, 4, 2), "I"), ((1 << 18, 4, 2), "linear"), ((1 << 18, 8, 2), "circular"),
+                                        ((1 << 18, 1, 2), "intensity"), ((1 << 19, 16), "intensity"), ((1 << 18, 64, 2), "I"),
+                                        ((1 << 18, 3, 2), "I")])
+def test_detect_in_the_last_layout_pass(shape, mode):
+    """nscrunch = 1: to_intensity / to_stokes of the dedispersed voltages at full time resolution, computed by the last layout
+    pass from the planar workspace (k_reinterleave_p2<.., DET>; the rows beyond the last whole tile by k_detect_planar) -- the
+    voltages are never stored.  (3 channels x 2 pols is not a power-of-two series count: the two-step form.)"""
+    dm, sr, fc = 12.0, 1e6, 1e9
+    x = orc.synthetic_block(shape, 33)
+    z = make_signal(x, sr, fc)
+    yr, s0, _ = orc.coherent_dedispersion(x, dm, sr, fc)
+    want = orc.to_intensity(yr) if mode == "intensity" else (orc.to_stokes(yr, "linear")[:, :, 0] if mode == "I" else orc.to_stokes(yr, mode))
+    for dev in (False, True):
+        got, start = pb.dedisperse_detect(z.to_device() if dev else z, pb.DM(dm), mode=mode, nscrunch=1)
+        got = np.asarray(got)
+        if len(shape) == 2:
+            got = got[..., 0]   # (dedisperse_detect reports an explicit polarisation axis of one)
+        assert start == s0 and got.shape == want.shape and got.dtype == np.float32
+        assert np.abs(got - want).max() < 3e-5 * np.abs(want).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("log2n,mode,nscrunch,dm", [(22, "I", 1024, 30.0), (22, "intensity", 64, 5.0), (23, "I", 256, 56.77),
                                                     (23, "intensity", 16384, 10.0), (22, "I", 4096, 0.7)])
 def test_detect_inside_the_column_pass_wider_tiles(log2n, mode, nscrunch, dm):
