@@ -240,7 +240,8 @@ int pbh_node_import(int device, const pbh_ipc_handle_t* handle, void** dev_ptr);
 int pbh_node_release(int device, void* dev_ptr);
 
 /* pbh_dedisperse_detect (below) for a device-resident input with a stated layout; out is the C-contiguous
- * detected array.  A series-major input needs the fused tail (nscrunch % 64 == 0): 4 kernels.            */
+ * detected array.  A series-major input needs a fused tail (nscrunch % 64 == 0, or nscrunch == 1 where the last
+ * layout pass detects; PBH_ERR_UNSUPPORTED otherwise): 4 kernels.                                           */
 int pbh_dedisperse_detect_layout(pbh_plan* plan, const void* in_dev, int in_layout, int64_t in_pitch,
                                  void* out_f32_dev, int nscrunch, int mode);
 

@@ -513,9 +513,12 @@ class Plan:
             pitch = x.series_major_pitch()
             if pitch is None:
                 raise ValueError("device input must be C-contiguous or series-major; call .contiguous()")
-            _check(lib().pbh_dedisperse_detect_layout(self._h, C.c_void_p(x.raw_ptr()), 1, int(pitch),
-                                                      C.c_void_p(out.data_ptr()), int(nscrunch), m))
-            return out
+            rc = lib().pbh_dedisperse_detect_layout(self._h, C.c_void_p(x.raw_ptr()), 1, int(pitch),
+                                                    C.c_void_p(out.data_ptr()), int(nscrunch), m)
+            if rc != -2:      # PBH_ERR_UNSUPPORTED: this geometry detects from a sample-major block only
+                _check(rc)
+                return out
+            x = x.contiguous()
         pin, lin = _ptr_loc(x)
         pout, lout = _ptr_loc(out)
         _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))

@@ -3059,9 +3059,9 @@ int pbh_dedisperse_detect_layout(pbh_plan* p, const void* in_dev, int in_layout,
     if (in_layout == PBH_LAYOUT_SERIES_MAJOR) {
         if (in_pitch < p->N) return fail(PBH_ERR_INVALID, "in_pitch < nsample");
         if ((!p->mixed && (p->bsL || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0)) ||
-            p->N >= (1LL << 31) || nscrunch % 64 != 0 ||
+            p->N >= (1LL << 31) || !(nscrunch % 64 == 0 || can_fuse_detect(p, nscrunch, mode)) ||
             p->nchan > 65535)
-            return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass power-of-two plan and nscrunch % 64 == 0");
+            return fail(PBH_ERR_UNSUPPORTED, "series-major input needs a multi-pass plan and a fused detect tail (nscrunch % 64 == 0, or 1)");
     } else {
         return pbh_dedisperse_detect(p, in_dev, out_dev, nscrunch, mode, PBH_DEVICE, PBH_DEVICE);
     }

@@ -280,8 +280,9 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     scrunch function; SURVEY.md 8a row 9 defines it.  Returns a float32 array (numpy or
     DeviceArray) and the crop start, not a Signal, since the sample rate changes.
     """
-    # a series-major device array goes through as it is when the fused tail applies (nscrunch % 64 == 0)
-    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant, allow_series=int(nscrunch) % 64 == 0)
+    # a series-major device array goes through as it is when a fused tail applies (nscrunch % 64 == 0, or 1; the plan falls
+    # back to a sample-major copy for the geometries whose tail is not fused)
+    plan, x, start, stop = _prepare(z, DM, ref_freq, chirp, variant, allow_series=int(nscrunch) % 64 == 0 or int(nscrunch) == 1)
     if plan.nchan != z.nchan:
         # a chirp that differs between polarisations runs as nchan*npol single-pol channels: detection needs the
         # (channel, pol) structure back, so it is a pass of its own here

@@ -673,6 +673,12 @@ def test_detect_in_the_last_layout_pass(shape, mode):
             got = got[..., 0]   # (dedisperse_detect reports an explicit polarisation axis of one)
         assert start == s0 and got.shape == want.shape and got.dtype == np.float32
         assert np.abs(got - want).max() < 3e-5 * np.abs(want).max()
+    # a series-major device array: read by the first column pass as it is (the non-power-of-two series count falls back to a copy)
+    zd = z.to_device()
+    zs = type(zd).like(zd, zd.data.to_series_major())
+    got_s, start_s = pb.dedisperse_detect(zs, pb.DM(dm), mode=mode, nscrunch=1)
+    got_s = np.asarray(got_s)
+    assert start_s == s0 and np.abs((got_s[..., 0] if len(shape) == 2 else got_s) - want).max() < 3e-5 * np.abs(want).max()
 
 
 @pytest.mark.gpu
