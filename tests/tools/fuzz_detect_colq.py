@@ -1,7 +1,7 @@
 """Randomised check of the detection inside the inverse column pass (k_colq<1024, INV, DET> + k_detect_reduce; test
 infrastructure, a few tens of ms per case on the GPU box): blocks of 2^22, 2^23 and 2^24 samples with random channel / polarisation counts,
 DMs (crop starts of every residue mod 16, crops from a few rows to most of the block), reference frequencies, scrunch
-factors 64 ... 16384 and both fusable modes, sample-major and series-major input, against the scrunched power of the
+factors 1 (the detecting layout pass) and 64 ... 16384, every detect mode, sample-major and series-major input, against the scrunched power of the
 voltages the ordinary call returns (float64 sums on the host).
 usage: python tests/tools/fuzz_detect_colq.py [seconds] [seed]"""
 import sys, time
@@ -24,8 +24,8 @@ while time.time() < t_end:
     sr = float(rng.choice([1e6, 6.25e6, 50e6]))
     fc = float(rng.uniform(0.4e9, 2e9))
     dm = float(10 ** rng.uniform(-1, 3))
-    mode = "I" if npol == 2 and rng.random() < 0.6 else "intensity"
-    ns = 1 << int(rng.integers(6, 15))
+    mode = str(rng.choice(["I", "I", "intensity", "linear", "circular"])) if npol == 2 else "intensity"
+    ns = 1 if rng.random() < 0.25 else 1 << int(rng.integers(6, 15))   # 1: the last layout pass detects (k_reinterleave_p2<.., DET>)
     r = rng.random()
     rf = None if r < 0.6 else (fc + sr * nchan / 2 if r < 0.8 else fc - sr * nchan / 2) * u.Hz
     shape = (n, nchan) + ((2,) if npol == 2 else ())
@@ -43,15 +43,23 @@ while time.time() < t_end:
     yt = y.data.tensor.reshape(len(y), nchan, npol)
     nout = len(y) // ns
     pw = (yt.real.double() ** 2 + yt.imag.double() ** 2)[:nout * ns].reshape(nout, ns, nchan, npol).sum(1)
-    want = (pw.sum(-1) if mode == "I" else (pw if npol == 2 else pw[..., 0])).cpu().numpy()
+    scale = pw.sum(-1, keepdim=True).cpu().numpy()
+    if mode in ("linear", "circular"):   # all four parameters (core.py:930-966)
+        ab = (yt[..., 0].conj().to(torch.complex128) * yt[..., 1].to(torch.complex128))[:nout * ns].reshape(nout, ns, nchan).sum(1)
+        d = pw[..., 0] - pw[..., 1]
+        quv = (d, 2 * ab.real, 2 * ab.imag) if mode == "linear" else (2 * ab.real, 2 * ab.imag, d)
+        want = torch.stack((pw.sum(-1),) + quv, dim=-1).cpu().numpy()
+    else:
+        want = (pw.sum(-1) if mode == "I" else (pw if npol == 2 else pw[..., 0])).cpu().numpy()
+        scale = want
     got, start = pb.dedisperse_detect(z, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=ns)
     got = np.asarray(got).reshape(want.shape)
     zs = type(z).like(z, z.data.to_series_major())
     got_s, _ = pb.dedisperse_detect(zs, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=ns)
-    err = float(np.max(np.abs(got - want) / want))
+    err = float(np.max(np.abs(got - want) / scale))
     # (one or two series run the 3-pass variant from a sample-major block and detect in a pass of their own: the two results
     #  are then sums in different orders, not the same bits)
-    same = float(np.max(np.abs(np.asarray(got_s).reshape(want.shape) - want) / want)) < 3e-5
+    same = float(np.max(np.abs(np.asarray(got_s).reshape(want.shape) - want) / scale)) < 3e-5
     residues.add(start % 16)
     cases += 1
     if not (err < 3e-5 and same):
