@@ -248,7 +248,7 @@ int pbh_dedisperse_detect_layout(pbh_plan* plan, const void* in_dev, int in_layo
 /* Same, followed by detection (core.py:766-774 / 930-966) and an nscrunch-fold sum over time of the
  * cropped samples (tail dropped): out is float32 (nout, nchan[, npol|4]), nout = (stop-start)/nscrunch.
  * The dedispersed voltages are not stored: with nscrunch % 64 == 0 a read pass over the planar workspace detects
- * them, and for |z|^2 / Stokes I at nsample = 2^22 ... 2^24 (256- to 1024-row column tiles, nscrunch a divisor of 2^14) the inverse
+ * them, and for |z|^2 / Stokes I at nsample = 2^20 ... 2^24 (64- to 1024-row column tiles, nscrunch a divisor of 2^14) the inverse
  * column pass itself does (4 KiB of partial sums per tile instead of 128 KiB of voltages; PBH_DETECT_COLQ=0 to
  * compare).  The plan then holds S * nsample / 16 floats of partial sums beside its workspace.  With nscrunch == 1
  * (to_intensity / to_stokes at full time resolution) the last layout pass of a power-of-two plan with 2 ... 128

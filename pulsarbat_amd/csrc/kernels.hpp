@@ -176,7 +176,7 @@ struct ColpParams {
     int64_t ld_plane = 0;
     int64_t st_shift = 0;
     int P = 1;  // column transform split P x M (k_radix_p did the radix-P stage): a series is P blocks of M rows
-    // DET (OP_TW_INV, F = 16, 32 or 64 columns, P = 1): the pass stores no voltages.  Each tile leaves |z|^2 summed over every
+    // DET (OP_TW_INV, F = 16 ... 256 columns, P = 1): the pass stores no voltages.  Each tile leaves |z|^2 summed over every
     // 16 of its columns, one float per row, in det_part[(series * N2/16 + g16) * M + tau * R + i] (row = tau + (M/R) i); a column group that holds
     // a scrunch boundary (time index == crop_start mod det_ns) inside it leaves the columns before the boundary there and
     // the rest in det_side[(series * (N2/det_ns) + boundary) * M + ...].  k_detect_reduce sums them per output sample.
@@ -228,7 +228,7 @@ __device__ __forceinline__ float2 treduce16x32(const float* a, int f) {
 template <int M, int OP, int R, bool DET = false>
 __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     constexpr int F = kTilePoints / M;
-    static_assert(!DET || (OP == OP_TW_INV && F % 16 == 0 && F <= 64 && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
+    static_assert(!DET || (OP == OP_TW_INV && F % 16 == 0 && M >= 2 * R && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];

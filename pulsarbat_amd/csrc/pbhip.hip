@@ -382,7 +382,7 @@ static int colp_mode() {
     return m;
 }
 #ifndef PBH_F64
-// the inverse column pass that detects instead of storing (N1 = 256, 512, 1024: tiles of 64, 32, 16 columns)
+// the inverse column pass that detects instead of storing (N1 = 64 ... 1024: tiles of 256 ... 16 columns)
 static int launch_colq_det(int M, ColpParams prm, hipStream_t st) {
     const int F = kTilePoints / M;
     prm.order = 0;
@@ -391,10 +391,10 @@ static int launch_colq_det(int M, ColpParams prm, hipStream_t st) {
     if (colp_mode() < 2) prm.counter = nullptr;
     switch (M) {
 #define X(m) case m: return launch_tile_kernel(k_colq<m, OP_TW_INV, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
-        X(256) X(512) X(1024)
+        X(64) X(128) X(256) X(512) X(1024)
 #undef X
     }
-    return fail(PBH_ERR_UNSUPPORTED, "detecting column pass: 256, 512 or 1024 rows");
+    return fail(PBH_ERR_UNSUPPORTED, "detecting column pass: 64 ... 1024 rows");
 }
 #endif
 template <int OP>
@@ -1309,7 +1309,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 #ifndef PBH_F64
         // Detect tail inside this pass: the dedispersed voltages are never stored (saves their write and the read of
         // k_detect_planar: 2 x 8 of the 60 bytes per sample of configs[4]).
-        if (tail.out && tail.mode <= PBH_DETECT_STOKES_I && detect_in_colq() && colp && P == 1 && (Q == 256 || Q == 512 || Q == 1024) && PBH_R == 32 && !workB &&
+        if (tail.out && tail.mode <= PBH_DETECT_STOKES_I && detect_in_colq() && colp && P == 1 && Q >= 64 && Q <= 1024 && PBH_R == 32 && !workB &&
             N2 % tail.nscrunch == 0 && tail.nscrunch % (kTilePoints / Q) == 0 && (stop - start) / tail.nscrunch > 0) {
             const int ns = tail.nscrunch, nchan = p->nchan, npol = p->npol, mode = tail.mode;
             const size_t npart = (size_t)S * (size_t)(N2 / 16) * (size_t)Q, nside = (size_t)S * (size_t)(N2 / ns) * (size_t)Q;

@@ -683,9 +683,10 @@ def test_detect_in_the_last_layout_pass(shape, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("log2n,mode,nscrunch,dm", [(22, "I", 1024, 30.0), (22, "intensity", 64, 5.0), (23, "I", 256, 56.77),
-                                                    (23, "intensity", 16384, 10.0), (22, "I", 4096, 0.7)])
+                                                    (23, "intensity", 16384, 10.0), (22, "I", 4096, 0.7),
+                                                    (21, "I", 1024, 3.0), (20, "intensity", 256, 1.5), (20, "I", 2048, 0.4)])
 def test_detect_inside_the_column_pass_wider_tiles(log2n, mode, nscrunch, dm):
-    """The same for 2^22 and 2^23 samples (256- and 512-row column tiles of 64 and 32 columns: four and two 16-column groups per
+    """The same for 2^20 ... 2^23 samples (64- to 512-row column tiles of 256 to 32 columns: sixteen to two 16-column groups per
     tile, the scrunch boundary inside any of them), against the oracle."""
     n, nchan, npol, sr, fc = 1 << log2n, 3, 2, 10e6, 1.2e9
     x = orc.synthetic_block((n, nchan, npol), 71)

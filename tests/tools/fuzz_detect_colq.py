@@ -18,7 +18,7 @@ t_end = time.time() + budget
 cases = bad = 0
 residues = set()
 while time.time() < t_end:
-    n = 1 << int(rng.choice([22, 23, 24]))   # 256-, 512- and 1024-row column tiles (64, 32, 16 columns)
+    n = 1 << int(rng.choice([20, 21, 22, 23, 24]))   # 64- to 1024-row column tiles (256 to 16 columns)
     nchan = int(rng.integers(1, 4))
     npol = int(rng.choice([1, 2]))
     sr = float(rng.choice([1e6, 6.25e6, 50e6]))
