@@ -276,6 +276,15 @@ int pbh_dedisperse_stream(pbh_plan* plan, const void* host_in, int64_t total_nsa
 #define PBH_STREAM_NSTATS 8
 int pbh_stream_stats(const pbh_plan* plan, double* out, int n);
 
+/* Detected output for the streaming calls: after pbh_plan_stream_detect(plan, mode, nscrunch) every chunk of
+ * pbh_dedisperse_stream / _raw ends in the fused detect tail of pbh_dedisperse_detect and host_out receives float32 rows
+ * (nchunk * hop / nscrunch, nchan[, npol | 4]) instead of voltages: the concatenation of the chunks' detected, scrunched
+ * valid regions = detect + scrunch of the dedispersed stream (to_intensity / to_stokes, core.py:766-774, 930-966, then the
+ * nscrunch-fold sum).  Needs hop = crop_stop - crop_start to be a multiple of nscrunch (PBH_ERR_INVALID otherwise) and a
+ * fused tail for the plan (multi-pass plans; nscrunch % 64 == 0, or 1: PBH_ERR_UNSUPPORTED otherwise).  mode < 0 switches
+ * back to voltages.  The download shrinks by 2 * nscrunch * npol / elements per row: the stream is then bound by its upload. */
+int pbh_plan_stream_detect(pbh_plan* plan, int mode, int nscrunch);
+
 /* ---- reader-side decode ----------------------------------------------------------------------- */
 /* Replaces the host post-processing of the reference's baseband readers
  * (pulsarbat/readers/_baseband_readers.py:136-153 `_read_baseband`: per-series sideband conjugation and

@@ -109,6 +109,7 @@ SIGNATURES = {
     "pbh_node_share_import": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pbh_node_share_free": (C.c_int, [C.c_int, C.c_void_p]),
     "pbh_stream_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "pbh_plan_stream_detect": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pbh_dedisperse_stream_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_RawLayout), C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int64),
                                             C.POINTER(C.c_float)]),
@@ -524,6 +525,25 @@ class Plan:
         _check(lib().pbh_dedisperse_detect(self._h, pin, pout, int(nscrunch), m, lin, lout))
         return out
 
+    def stream_detect(self, mode=None, nscrunch=1):
+        """Make the streaming calls write detected rows (``pbh_plan_stream_detect``): ``mode`` one of DETECT_MODES, or None
+        for voltages again.  Returns the shape of one chunk's output rows beyond the time axis."""
+        if mode is None:
+            _check(lib().pbh_plan_stream_detect(self._h, -1, 1))
+            self._stream_tail = None
+            return None
+        m = DETECT_MODES[mode]
+        _check(lib().pbh_plan_stream_detect(self._h, m, int(nscrunch)))
+        self._stream_tail = (int(nscrunch), {0: (self.nchan, self.npol), 1: (self.nchan,), 2: (self.nchan, 4), 3: (self.nchan, 4)}[m])
+        return self._stream_tail[1]
+
+    def _stream_out(self, nchunk, sample_shape):
+        """Host array a streaming call fills: voltages, or the detected rows stream_detect asked for."""
+        tail = getattr(self, "_stream_tail", None)
+        if tail is None:
+            return np.empty((nchunk * self.nout,) + tuple(sample_shape), dtype=self.dtype)
+        return np.empty((nchunk * (self.nout // tail[0]),) + tail[1], dtype=self.real_dtype)
+
     def dedisperse_stream(self, x_host, out=None):
         """Overlap-save over a long host block: (total, nchan, npol) c64 -> (nchunk*hop, ...), plus ms."""
         if not isinstance(x_host, np.ndarray) or x_host.dtype != self.dtype or not x_host.flags.c_contiguous:
@@ -535,7 +555,7 @@ class Plan:
             raise ValueError("empty valid region or input shorter than one chunk")
         nchunk = (x_host.shape[0] - self.nsample) // hop + 1
         if out is None:
-            out = np.empty((nchunk * hop,) + tuple(x_host.shape[1:]), dtype=self.dtype)
+            out = self._stream_out(nchunk, x_host.shape[1:])
         self._sync_stream()
         n, ms = C.c_int64(), C.c_float()
         _check(lib().pbh_dedisperse_stream(self._h, C.c_void_p(x_host.ctypes.data), int(x_host.shape[0]),
@@ -566,7 +586,7 @@ class Plan:
             raise ValueError("empty valid region or input shorter than one chunk")
         nchunk = (int(total_nsample) - self.nsample) // hop + 1
         if out is None:
-            out = np.empty((nchunk * hop, self.nchan, self.npol), dtype=np.complex64)
+            out = self._stream_out(nchunk, (self.nchan, self.npol))
         lay = _RawLayout(**{k: int(v) for k, v in layout.items()})
         mask = None
         if conj is not None:

@@ -39,6 +39,7 @@
 #define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
 #define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
 #define pbh_stream_stats PBH_FN(stream_stats)
+#define pbh_plan_stream_detect PBH_FN(plan_stream_detect)
 #define pbh_dedisperse_istft PBH_FN(dedisperse_istft)
 #define pbh_real_to_complex PBH_FN(real_to_complex)
 #define pbh_detect PBH_FN(detect)
@@ -272,6 +273,7 @@ struct pbh_plan {
     bool rowmix = false;
     MixTable mixR;
     double stream_stats[PBH_STREAM_NSTATS] = {};   // of the last streaming call (pbh_stream_stats)
+    int stream_detect_mode = -1, stream_detect_ns = 1;   // pbh_plan_stream_detect: the streaming calls write detected rows
     double gen_coeff = 0, gen_inv_ndt = 0, gen_inv_ref = 0;   // parameters of the generated chirp (k_rowp16's on-the-fly phase)
     bool chirp_lazy = false;   // the generated chirp exists as phase rows only; `chirp` is filled by materialize_chirp on demand
 };
@@ -3684,6 +3686,43 @@ static int64_t stream_epoch_chunks(size_t first_bytes, size_t step_bytes, int64_
 }
 }  // namespace
 
+// Detected output of the streaming calls (pbh_plan_stream_detect): every chunk ends in the fused detect tail and what goes
+// back to the host is float32 (hop / nscrunch, nchan[, npol | 4]) rows -- a filterbank stream; the chunks' valid regions
+// must be whole scrunch blocks (hop % nscrunch == 0) for the concatenation to be the scrunched stream.
+int pbh_plan_stream_detect(pbh_plan* p, int mode, int nscrunch) {
+    if (!p) return fail(PBH_ERR_INVALID, "plan is NULL");
+    if (mode < 0) {
+        p->stream_detect_mode = -1;
+        p->stream_detect_ns = 1;
+        return PBH_OK;
+    }
+    if (nscrunch <= 0) return fail(PBH_ERR_INVALID, "nscrunch must be positive");
+    if (!detect_out_elems(mode, p->npol)) return fail(PBH_ERR_INVALID, "bad detect mode");
+    if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
+    if ((p->stop - p->start) % nscrunch != 0)
+        return fail(PBH_ERR_INVALID, "the plan's valid region (crop_stop - crop_start) must be a multiple of nscrunch");
+    if (!can_fuse_detect(p, nscrunch, mode))
+        return fail(PBH_ERR_UNSUPPORTED, "no fused detect tail for this plan and nscrunch (multi-pass plans; nscrunch % 64 == 0, or 1)");
+    p->stream_detect_mode = mode;
+    p->stream_detect_ns = nscrunch;
+    return PBH_OK;
+}
+// bytes one chunk of a streaming call leaves, and the tail that makes them
+static size_t stream_out_bytes(const pbh_plan* p) {
+    const int64_t hop = p->stop - p->start;
+    if (p->stream_detect_mode < 0) return sizeof(cf) * (size_t)p->S * (size_t)hop;
+    return sizeof(real) * (size_t)(hop / p->stream_detect_ns) * (size_t)p->nchan * (size_t)detect_out_elems(p->stream_detect_mode, p->npol);
+}
+static DetectTail stream_tail(const pbh_plan* p, void* dout) {
+    DetectTail t;
+    if (p->stream_detect_mode >= 0) {
+        t.out = (real*)dout;
+        t.mode = p->stream_detect_mode;
+        t.nscrunch = p->stream_detect_ns;
+    }
+    return t;
+}
+
 int pbh_stream_stats(const pbh_plan* p, double* out, int n) {
     if (!p || !out || n < 0) return fail(PBH_ERR_INVALID, "NULL argument");
     for (int i = 0; i < n; ++i) out[i] = i < PBH_STREAM_NSTATS ? p->stream_stats[i] : 0.0;
@@ -3700,7 +3739,7 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsampl
     const int64_t nchunk = (total_nsample - N) / hop + 1;
     HIPCHECK(hipSetDevice(p->device));
     const size_t row = sizeof(cf) * (size_t)p->S;
-    const size_t out_bytes = row * (size_t)hop, step = row * (size_t)hop, keep = row * (size_t)(N - hop);
+    const size_t out_bytes = stream_out_bytes(p), step = row * (size_t)hop, keep = row * (size_t)(N - hop);
     const size_t host_in_bytes = row * (size_t)total_nsample, host_out_bytes = out_bytes * (size_t)nchunk;
     // a chunk starts j*hop rows into its window: the layout kernels want that on a 16-byte boundary, else one chunk per epoch
     const int64_t B = step % 16 == 0 ? stream_epoch_chunks(row * (size_t)N, step, nchunk) : 1;
@@ -3750,7 +3789,8 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsampl
                 rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
             }
             if (rc == PBH_OK) {
-                auto steps = build_steps(p, (const cf*)(win + (size_t)j * step), (cf*)dout[b]);
+                const DetectTail tail = stream_tail(p, dout[b]);
+                auto steps = build_steps(p, (const cf*)(win + (size_t)j * step), tail.out ? nullptr : (cf*)dout[b], tail);
                 rc = run_steps(steps, rig.s_cmp);
             }
             rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
@@ -3823,7 +3863,7 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
     const bool sm = !(p->bsL || p->mixed || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                       p->N >= (1LL << 31)) && p->S > 1;
     const size_t row = sizeof(cf) * (size_t)p->S;
-    const size_t out_bytes = row * (size_t)hop, host_out_bytes = out_bytes * (size_t)nchunk;
+    const size_t out_bytes = stream_out_bytes(p), host_out_bytes = out_bytes * (size_t)nchunk;
     const int nwin = epochs.size() > 1 ? 2 : 1;
 
     void* dwin[2] = {nullptr, nullptr};
@@ -3891,7 +3931,8 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
                 rc = decode_launch(win, (int64_t)ep.base, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
                                    sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, rig.s_cmp);
             if (rc == PBH_OK) {
-                auto steps = build_steps(p, (const cf*)dec, (cf*)dout[b], DetectTail(), io);
+                const DetectTail tail = stream_tail(p, dout[b]);
+                auto steps = build_steps(p, (const cf*)dec, tail.out ? nullptr : (cf*)dout[b], tail, io);
                 rc = run_steps(steps, rig.s_cmp);
             }
             rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");

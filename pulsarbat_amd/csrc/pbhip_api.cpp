@@ -45,6 +45,7 @@
     int P##dedisperse_detect(P##plan*, const void*, void*, int, int, int, int);                                 \
     int P##dedisperse_stream(P##plan*, const void*, int64_t, void*, int64_t*, float*);                          \
     int P##stream_stats(const P##plan*, double*, int);                                                          \
+    int P##plan_stream_detect(P##plan*, int, int);                                                              \
     int P##dedisperse_stream_raw(P##plan*, const void*, size_t, const pbh_raw_layout_t*, int64_t, int64_t,      \
                                  const unsigned char*, float, void*, int64_t*, float*);                         \
     int P##detect(int, void*, int, const void*, void*, int64_t, int, int, int, int, int, int);                  \
@@ -218,6 +219,9 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* in, int64_t total, void* out,
 }
 int pbh_stream_stats(const pbh_plan* p, double* out, int n) {
     FORWARD(p, pbh32_stream_stats(P32(p), out, n), pbh64_stream_stats(P64(p), out, n));
+}
+int pbh_plan_stream_detect(pbh_plan* p, int mode, int nscrunch) {
+    FORWARD(p, pbh32_plan_stream_detect(P32(p), mode, nscrunch), pbh64_plan_stream_detect(P64(p), mode, nscrunch));
 }
 int pbh_dedisperse_stream_raw(pbh_plan* p, const void* raw, size_t raw_bytes, const pbh_raw_layout_t* layout, int64_t first,
                               int64_t total, const unsigned char* conj_mask, float scale, void* out, int64_t* nchunk, float* ms) {

@@ -291,7 +291,8 @@ def dedisperse_detect(z, DM, /, *, ref_freq=None, chirp=None, mode="I", nscrunch
     return plan.dedisperse_detect(x, nscrunch=nscrunch, mode=mode), start
 
 
-def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto", offset=0, n=None, channels=None):
+def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="auto", offset=0, n=None, channels=None,
+                                 detect=None, nscrunch=1):
     """Overlap-save dedispersion of a long host-resident signal in chunks of ``chunk`` samples.
 
     Equals ``pb.concatenate([coherent_dedispersion(z[k*hop : k*hop + chunk], DM, ref_freq=ref)
@@ -307,10 +308,18 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
     ``shard.channel_slice(nchan, world, rank)``) streams a rank's share of a channel-sharded job: the result equals the
     full stream's ``[:, channels]`` -- crop and reference frequency are the FULL band's (dedispersion.py:118-131), the
     chirp the subset's -- and for channel-major files only that share of the payload is read and uploaded.
+
+    ``detect`` ("intensity", "I", "linear", "circular") makes it a filterbank stream: every chunk ends in the fused detect
+    tail of ``dedisperse_detect`` and what comes back is ``(float32 array (nchunk * hop / nscrunch, nchan[, npol | 4]),
+    crop start, ms)`` -- ``to_intensity`` / ``to_stokes`` of the dedispersed stream summed over ``nscrunch`` samples, the
+    voltages never leave the GPU.  A chunk's valid region is shortened to a whole number of scrunch blocks, so the chunks
+    stay contiguous in time.
     """
     from ..readers import BasebandReader
+    if detect is not None and (int(nscrunch) != 1 and int(nscrunch) % 64 != 0):
+        raise ValueError("a detected stream needs nscrunch == 1 or a multiple of 64 (the fused detect tails)")
     if isinstance(z, BasebandReader):
-        return _stream_from_reader(z, DM, chunk, ref_freq, variant, offset, n, channels)
+        return _stream_from_reader(z, DM, chunk, ref_freq, variant, offset, n, channels, detect, int(nscrunch))
     if channels is not None:
         raise TypeError("channels= applies to streaming from a reader; slice a signal with z[:, channels]")
     if not isinstance(z, BasebandSignal):
@@ -323,12 +332,21 @@ def coherent_dedispersion_stream(z, DM, /, *, chunk, ref_freq=None, variant="aut
         ref_freq = z.center_freq
     head = z[:chunk]
     start, stop = _crop_bounds(head, DM, ref_freq)
+    if detect is not None:
+        stop -= (stop - start) % int(nscrunch)
     plan, _ = _plan_for(head, DM, ref_freq, (start, stop), variant=variant)
-    y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
-    return type(z).like(z, y, **_advance(z, start)), ms
+    if detect is None:
+        y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
+        return type(z).like(z, y, **_advance(z, start)), ms
+    plan.stream_detect(detect, nscrunch)
+    try:   # (plans are cached and shared: the tail is this call's)
+        y, ms = plan.dedisperse_stream(np.ascontiguousarray(z.data))
+    finally:
+        plan.stream_detect(None)
+    return y, start, ms
 
 
-def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n, channels=None):
+def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n, channels=None, detect=None, nscrunch=1):
     if not issubclass(reader._signal_type, BasebandSignal) or reader.intensity or not reader.complex_data:
         raise TypeError("streaming from a reader needs complex voltage data in a BasebandSignal type")
     n = len(reader) - offset if n is None else n
@@ -341,6 +359,8 @@ def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n, channel
     if ref_freq is None:
         ref_freq = head.center_freq
     start, stop = _crop_bounds(head, DM, ref_freq)          # the FULL band's, whatever the channel subset
+    if detect is not None:
+        stop -= (stop - start) % nscrunch
     if channels is not None:
         if not isinstance(channels, slice) or channels.step not in (None, 1):
             raise TypeError("channels must be a contiguous slice")
@@ -362,6 +382,13 @@ def _stream_from_reader(reader, DM, chunk, ref_freq, variant, offset, n, channel
     buf, first = reader._raw.fetch(offset, n, byte_range=byte_range)
     if mask is not None:
         mask = np.asarray(mask).reshape(plan.nchan, plan.npol)
+    if detect is not None:
+        plan.stream_detect(detect, nscrunch)
+        try:
+            y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask, scale=reader._raw.scale)
+        finally:
+            plan.stream_detect(None)
+        return y, start, ms
     y, ms = plan.dedisperse_stream_raw(buf, lay, n, first=first, conj=mask, scale=reader._raw.scale)
     y = y.reshape((len(y),) + tuple(head.shape[1:]))
     return type(head).like(head, y, **_advance(head, start)), ms

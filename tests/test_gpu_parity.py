@@ -368,6 +368,42 @@ def test_detect_scrunch_modes(mode, k):
     assert np.abs(got - want).max() < 3e-5 * scale * max(1.0, np.sqrt(k) / 4)
 
 
+@pytest.mark.parametrize("shape,chunk,dm,mode,ns", [((1 << 21, 2, 2), 1 << 18, 30.0, "I", 64), ((1 << 21, 2, 2), 1 << 18, 30.0, "linear", 1),
+                                                    ((3 << 19, 4), 1 << 17, 10.0, "intensity", 128),
+                                                    ((1 << 22, 2, 2), 1 << 20, 80.0, "I", 1024),     # the detecting column pass
+                                                    ((1 << 21, 2, 2), 1 << 18, 30.0, "circular", 256)])
+def test_stream_detected(shape, chunk, dm, mode, ns):
+    """A filterbank stream (pbh_plan_stream_detect): the detected, scrunched valid regions of the chunks, contiguous in time --
+    detect + scrunch of what the voltage stream returns for the same (shortened) valid region, chunk by chunk, and the
+    download is the detected rows only."""
+    from pulsarbat_amd.transforms.dedispersion import _crop_bounds, _plan_for
+    sr, fc = 1e6, 1e9
+    x = orc.synthetic_block(shape, 23)
+    z = make_signal(x, sr, fc)
+    got, start, ms = pb.coherent_dedispersion_stream(z, pb.DM(dm), chunk=chunk, detect=mode, nscrunch=ns)
+    head = z[:chunk]
+    s0, s1 = _crop_bounds(head, pb.DM(dm), head.center_freq)
+    s1 -= (s1 - s0) % ns
+    hop = s1 - s0
+    nchunk = (shape[0] - chunk) // hop + 1
+    assert start == s0 and ms > 0 and len(got) == nchunk * (hop // ns) and got.dtype == np.float32
+    # the same chunks through the oracle (one reference call per chunk, cropped to the shortened valid region)
+    want = []
+    for k in range(nchunk):
+        yk = orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, sr, fc)[0][:hop]
+        d = orc.to_intensity(yk) if mode == "intensity" else (orc.to_stokes(yk, "linear")[:, :, 0] if mode == "I" else orc.to_stokes(yk, mode))
+        want.append(orc.scrunch(d, ns))
+    want = np.concatenate(want, axis=0)
+    assert got.reshape(want.shape).shape == want.shape
+    assert np.abs(got.reshape(want.shape) - want).max() < 3e-5 * np.abs(want).max() * max(1.0, np.sqrt(ns) / 4)
+    plan, _ = _plan_for(head, pb.DM(dm), head.center_freq, (s0, s1))
+    st = plan.stream_stats()
+    assert st["d2h_bytes"] == got.nbytes and st["h2d_bytes"] == x.nbytes - (shape[0] - (chunk + (nchunk - 1) * hop)) * x[0].nbytes
+    # ... and the plan is back to voltages for the next caller
+    y, _ = pb.coherent_dedispersion_stream(z[:chunk + hop], pb.DM(dm), chunk=chunk)
+    assert np.asarray(y).dtype == np.complex64
+
+
 @pytest.mark.parametrize("shape,chunk,dm", [((1 << 18, 4, 2), 1 << 15, 20.0), ((300000, 2, 2), 1 << 16, 50.0),
                                             ((1 << 16, 3), 1 << 14, 5.0),
                                             ((200000, 4, 2), 20000, 5.0), ((300000, 2, 2), 64800, 8.0)])   # 7-smooth chunks (k_colmix, one and two levels)

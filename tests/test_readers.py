@@ -354,6 +354,22 @@ class TestRawStream:
         assert y2.shape == y3.shape and y2.start_time.isclose(y3.start_time)
         assert np.linalg.norm(np.asarray(y2) - np.asarray(y3)) / np.linalg.norm(np.asarray(y3)) < 2e-6
 
+    def test_guppi_reader_stream_detected(self):
+        """A filterbank stream straight from the payload bytes: equals detect + scrunch of the voltage stream from the same
+        file over the same (shortened) valid regions."""
+        r = pbr.GUPPIRawReader(GUPPI)
+        chunk, dm, ns = 1 << 15, 0.5, 64
+        got, start, ms = pb.coherent_dedispersion_stream(r, pb.DM(dm), chunk=chunk, detect="I", nscrunch=ns)
+        x = ro.guppi_samples(GUPPI).transpose(0, 2, 1)
+        _, s0, s1 = orc.coherent_dedispersion(x[:chunk], dm, 3.125e6, 344.1875e6)
+        s1 -= (s1 - s0) % ns
+        hop = s1 - s0
+        nchunk = (len(x) - chunk) // hop + 1
+        want = np.concatenate([orc.scrunch(orc.to_stokes(orc.coherent_dedispersion(x[k * hop:k * hop + chunk], dm, 3.125e6, 344.1875e6)[0][:hop],
+                                                          "linear")[:, :, 0], ns) for k in range(nchunk)], axis=0)
+        assert start == s0 and ms > 0 and got.shape == want.shape
+        assert np.abs(got - want).max() < 3e-5 * np.abs(want).max()
+
     def test_sharded_reader_stream(self):
         """A rank's share of a channel-sharded stream from a file: ``channels=`` gives the full stream's ``[:, channels]``
         (full-band crop and reference frequency) while reading and uploading only that share of a channel-major file."""

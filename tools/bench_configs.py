@@ -53,8 +53,9 @@ def config5(steps=10):
             "Msamples_per_s_fused": ns / dt / 1e6, "ms_voltage_output": dt2 * 1e3,
             "alg_bytes_per_sample": 60.0, "GBps_at_60B": 60.0 * ns / dt / 1e9}
 
-def config4(total_log2=26, chunk_log2=22):
-    """BASELINE configs[3]: overlap-save stream from pinned host memory; every input row crosses PCIe once."""
+def config4(total_log2=26, chunk_log2=22, detect=None, nscrunch=1024):
+    """BASELINE configs[3]: overlap-save stream from pinned host memory; every input row crosses PCIe once.
+    detect: the same stream as a filterbank stream (pbh_plan_stream_detect): the download is the detected rows only."""
     nchan, npol, dm, band, center = 8, 2, 56.77, 400e6, 1.4e9
     sr = band / nchan
     n = 1 << chunk_log2
@@ -67,24 +68,31 @@ def config4(total_log2=26, chunk_log2=22):
     x = np.empty((total, nchan, npol), np.complex64)
     for k in range(total // blk):
         np.multiply(base, np.complex64(np.exp(0.37j * k) * (1 + 0.01 * k)), out=x[k * blk:(k + 1) * blk])
+    if detect:
+        stop -= (stop - start) % nscrunch
     plan = _hip.Plan(n, nchan, npol, start, stop)
     plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, center)
     hop = stop - start
-    out = np.empty((((total - n) // hop + 1) * hop, nchan, npol), np.complex64)
+    if detect:
+        tail = plan.stream_detect(detect, nscrunch)
+        out = np.empty((((total - n) // hop + 1) * (hop // nscrunch),) + tail, np.float32)
+    else:
+        out = np.empty((((total - n) // hop + 1) * hop, nchan, npol), np.complex64)
     out[::4096] = 0      # touch the pages: first-touch faults are the allocator's cost, not the stream's
     t0 = time.perf_counter()
     y, ms = plan.dedisperse_stream(x, out=out)
     wall = time.perf_counter() - t0
     st = plan.stream_stats()
     nchunk = st["nchunk"]
-    return {"config": f"configs[3]: 2^{total_log2} samples x 8 x 2 streamed in 2^{chunk_log2} chunks (overlap-save, upload once)",
+    what = f", Stokes-{detect} + {nscrunch}x scrunch inside every chunk (filterbank stream)" if detect else ""
+    return {"config": f"configs[3]: 2^{total_log2} samples x 8 x 2 streamed in 2^{chunk_log2} chunks (overlap-save, upload once){what}",
             "hop": hop, "nchunk": nchunk, "valid_fraction_of_a_chunk": hop / n, "ms_stream_events": ms,
             "wall_s_incl_pinning": wall, "H2D_GB": st["h2d_bytes"] / 1e9, "D2H_GB": st["d2h_bytes"] / 1e9,
             "input_GB": x.nbytes / 1e9, "H2D_GBps": st["h2d_GBps"], "D2H_GBps": st["d2h_GBps"],
             "h2d_ms": st["h2d_ms"], "d2h_ms": st["d2h_ms"], "kernel_ms": st["kernel_ms"],
             "kernel_ms_per_chunk": st["kernel_ms"] / nchunk, "d2d_GB": st["d2d_bytes"] / 1e9,
             "overlap_efficiency": st["overlap_efficiency"],
-            "valid_Msamples_per_s": len(y) * nchan * npol / (ms * 1e-3) / 1e6,
+            "valid_Msamples_per_s": nchunk * hop * nchan * npol / (ms * 1e-3) / 1e6,
             "input_Msamples_per_s": total * nchan * npol / (ms * 1e-3) / 1e6}
 
 if __name__ == "__main__":
@@ -95,3 +103,7 @@ if __name__ == "__main__":
         print(json.dumps(config4()), flush=True)
     if "4full" in which:
         print(json.dumps(config4(28)), flush=True)
+    if "4det" in which:
+        print(json.dumps(config4(26, detect="I")), flush=True)
+    if "4fulldet" in which:
+        print(json.dumps(config4(28, detect="I")), flush=True)
