@@ -161,7 +161,23 @@ def extra_configs3_stream(total_log2=26):
         plan.chirp_generate(DM / 2.41e-4 * 1e12, 1 / sr, freqs, CENTER_HZ)
         y, ms = plan.dedisperse_stream(x, out=out)
         st = plan.stream_stats()
-    return {"workload": "configs[3] bounded: 2^%d samples x 8 x 2 in 2^22-sample chunks, hop %d, %d chunks (full config: 2^28, "
+    # the same stream as a filterbank stream: configs[4]'s tail (Stokes I, 1024x) at the end of every chunk
+    fb = None
+    try:
+        ns = 1024
+        stop_fb = stop - (stop - start) % ns
+        with _hip.Plan(n, nchan, npol, start, stop_fb) as plan:
+            plan.chirp_generate(DM / 2.41e-4 * 1e12, 1 / sr, freqs, CENTER_HZ)
+            plan.stream_detect("I", ns)
+            yd, ms_fb = plan.dedisperse_stream(x)
+            sf = plan.stream_stats()
+        fb = {"workload": "the same stream with Stokes-I + 1024x scrunch inside every chunk (pbh_plan_stream_detect): float32 rows come back",
+              "ms_total": ms_fb, "h2d_GBps": sf["h2d_GBps"], "d2h_GB": sf["d2h_bytes"] / 1e9, "kernel_ms": sf["kernel_ms"],
+              "overlap_efficiency": sf["overlap_efficiency"], "out_shape": list(yd.shape),
+              "input_Msamples_per_s": float(total) * nchan * npol / ms_fb / 1e3}
+    except Exception as exc:   # an extra of an extra
+        fb = {"error": repr(exc)}
+    return {"filterbank_stream": fb, "workload": "configs[3] bounded: 2^%d samples x 8 x 2 in 2^22-sample chunks, hop %d, %d chunks (full config: 2^28, "
                         "430 chunks)" % (total_log2, hop, st["nchunk"]),
             "ms_total": ms, "input_GB": x.nbytes / 1e9, "h2d_GB": st["h2d_bytes"] / 1e9, "d2h_GB": st["d2h_bytes"] / 1e9,
             "h2d_GBps": st["h2d_GBps"], "d2h_GBps": st["d2h_GBps"], "kernel_ms": st["kernel_ms"],
