@@ -67,6 +67,36 @@ while time.time() < t_end:
             tol = 1e-5 if dtype == np.complex64 else 1e-8
             assert rel(y[k * hop:(k + 1) * hop], want) < tol, "stream differs from the oracle"
             ok["stream"] += 1
+            if dtype == np.complex64 and rng.random() < 0.5:   # ---- the same stream detected (pbh_plan_stream_detect)
+                ns = int(rng.choice([1, 64, 128, 256]))
+                mode = str(rng.choice(["intensity", "I", "linear", "circular"])) if len(tail) == 2 else "intensity"
+                stop2 = stop - (stop - start) % ns
+                if stop2 - start >= ns and total >= chunk:
+                    plan2, _ = _plan_for(head, pb.DM(dm), head.center_freq, (start, stop2))
+                    try:
+                        plan2.stream_detect(mode, ns)
+                    except NotImplementedError:
+                        plan2 = None          # no fused tail for this plan (one-tile, few series, 7-smooth with nscrunch 1 ...)
+                    if plan2 is not None:
+                        try:
+                            d, _ = plan2.dedisperse_stream(x)
+                        finally:
+                            plan2.stream_detect(None)
+                        v, _ = plan2.dedisperse_stream(x)          # the voltages over the same (shortened) valid regions
+                        v = v.reshape(len(v), nchan, -1)
+                        vd = v.astype(np.complex128)
+                        pw = vd.real ** 2 + vd.imag ** 2
+                        if mode == "intensity":
+                            w = pw
+                        else:
+                            ab = np.conj(vd[..., 0]) * vd[..., 1]
+                            dd = pw[..., 0] - pw[..., 1]
+                            w = {"I": pw.sum(-1), "linear": np.stack([pw.sum(-1), dd, 2 * ab.real, 2 * ab.imag], -1),
+                                 "circular": np.stack([pw.sum(-1), 2 * ab.real, 2 * ab.imag, dd], -1)}[mode]
+                        w = w.reshape((len(w) // ns, ns) + w.shape[1:]).sum(1)
+                        assert d.size == w.size, "detected stream: shape"
+                        assert np.abs(d.reshape(w.shape) - w).max() < 3e-5 * np.abs(w).max() * max(1.0, ns ** 0.5 / 4), "detected stream differs"
+                        ok["detected"] = ok.get("detected", 0) + 1
         elif which == 1:   # ---- raw 8-bit stream in blocks
             nchan, npol = int(rng.integers(1, 5)), int(rng.choice([1, 2]))
             blk_t = int(rng.integers(200, 5000))
