@@ -1131,7 +1131,13 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
             }
         }
-        if (tail.out) {
+        if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode)) {
+            const int nchan = p->nchan, npol = p->npol, mode = tail.mode;
+            real* dout = tail.out;
+            steps.push_back({"k_reint_detect", [=](hipStream_t st) {
+                return launch_reint_detect(work, dout, start, stop, S, nchan, npol, mode, N, st);
+            }});
+        } else if (tail.out) {
             const int nchan = p->nchan, npol = p->npol;
             const int64_t nout = (stop - start) / tail.nscrunch;
             steps.push_back({"k_detect_planar", [=](hipStream_t st) {
@@ -1420,8 +1426,8 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
     if (!(p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && p->nchan <= 65535)) return false;
     if (nscrunch % 64 == 0) return true;
-    // full time resolution: the power-of-two planar pipeline's last layout pass detects (launch_reint_detect)
-    return nscrunch == 1 && !p->mixed && !p->bsL && is_pow2(p->N) && reint_detect_ok(p->S, p->npol, mode);
+    // full time resolution: the last layout pass of the planar pipelines (2^k, m 2^k and 7-smooth lengths) detects (launch_reint_detect)
+    return nscrunch == 1 && !p->bsL && reint_detect_ok(p->S, p->npol, mode);
 }
 
 static int run_steps(std::vector<Step>& steps, hipStream_t st) {
