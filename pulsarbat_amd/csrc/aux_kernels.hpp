@@ -984,16 +984,18 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
 // (ColpParams::det_part / det_side).  Output sample o covers times [start + o ns, start + (o + 1) ns), t = r N2 + n2:
 // ns / 16 consecutive groups of one row (the run may continue in the next row), plus -- when start is not a multiple of 16
 // -- the columns behind the boundary of its first group (det_side) and the columns before the boundary of the group
-// after its last one (what det_part holds for a group with a boundary).  One thread per (row, interval of the row,
-// channel); consecutive threads follow the partial sums' row order (row = x / R + MR (x % R)): coalesced reads.
+// after its last one (what det_part holds for a group with a boundary).  Consecutive threads follow the partial sums'
+// row order (row = x / R + MR (x % R)): coalesced reads.
 //   mode 0: out[o][chan][pol];  mode 1 (Stokes I): out[o][chan], polarisations added.
 __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ part, const real* __restrict__ side,
                                                        real* __restrict__ out, int N2, int M, int R, int ns, int64_t start,
-                                                       int64_t nout, int nchan, int npol, int mode) {
-    // 64 rows x 4 quarters of an output's run of groups per workgroup (the quarters meet in LDS)
-    __shared__ real sh[4][64];
-    const int xl = threadIdx.x & 63, qu = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + xl;
+                                                       int64_t nout, int nchan, int npol, int mode, int parts) {
+    // 256 / parts rows x `parts` (1, 4 or 16) pieces of an output's run of groups per workgroup (the pieces meet in LDS):
+    // short runs (small scrunch factors) want many rows per workgroup, long ones many pieces
+    __shared__ real sh[256];
+    const int xw = 256 / parts;
+    const int xl = threadIdx.x % xw, qu = threadIdx.x / xw;
+    const int x = blockIdx.x * xw + xl;
     const int kk = blockIdx.y, chan = blockIdx.z;
     const int MR = M / R;
     const int r0 = x / R + MR * (x % R);
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ 
     const int g0 = (kk * ns + bmod - bcol) / 16;
     const int n0 = min(nj, ngrp - g0);
     const int xn = ((r0 + 1) % MR) * R + (r0 + 1) / MR;
-    const int per = (nj + 3) / 4, ja = max(1, qu * per), jb = min(nj, (qu + 1) * per);
+    const int per = (nj + parts - 1) / parts, ja = max(1, qu * per), jb = min(nj, (qu + 1) * per);
     real tot = 0;
     for (int pp = 0; pp < npol; ++pp) {
         const int s = chan * npol + pp;
@@ -1023,11 +1025,16 @@ __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ 
             }
             for (; j < jb; ++j) a[0] += at(j);
         }
-        __syncthreads();
-        sh[qu][xl] = (a[0] + a[1]) + (a[2] + a[3]);
-        __syncthreads();
+        real acc = (a[0] + a[1]) + (a[2] + a[3]);
+        if (parts > 1) {
+            __syncthreads();
+            sh[qu * xw + xl] = acc;
+            __syncthreads();
+            acc = 0;
+            if (qu == 0)
+                for (int q = 0; q < parts; ++q) acc += sh[q * xw + xl];
+        }
         if (qu == 0 && live) {
-            const real acc = (sh[0][xl] + sh[1][xl]) + (sh[2][xl] + sh[3][xl]);
             if (mode == 0) out[(o * nchan + chan) * npol + pp] = acc;
             tot += acc;
         }

@@ -1331,8 +1331,10 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 const ColpParams cpd = cp3;
                 steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colq_det(Q, cpd, st); }});
                 steps.push_back({"k_detect_reduce", [=](hipStream_t st) {
-                    hipLaunchKernelGGL(k_detect_reduce, dim3((unsigned)((Q + 63) / 64), (unsigned)(N2 / ns), (unsigned)nchan), dim3(256), 0, st,
-                                       (const real*)cpd.det_part, (const real*)cpd.det_side, dout, N2, Q, (int)PBH_R, ns, start, nout, nchan, npol, mode);
+                    const int nj = ns / 16 + 1, parts = nj <= 9 ? 1 : (nj <= 129 ? 4 : 16), xw = 256 / parts;
+                    hipLaunchKernelGGL(k_detect_reduce, dim3((unsigned)((Q + xw - 1) / xw), (unsigned)(N2 / ns), (unsigned)nchan), dim3(256), 0, st,
+                                       (const real*)cpd.det_part, (const real*)cpd.det_side, dout, N2, Q, (int)PBH_R, ns, start, nout, nchan, npol, mode,
+                                       parts);
                     HIPCHECK(hipGetLastError());
                     return (int)PBH_OK;
                 }});
