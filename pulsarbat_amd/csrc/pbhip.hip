@@ -257,6 +257,8 @@ struct pbh_plan {
     void* stage_in = nullptr;   // device staging for host inputs
     void* stage_out = nullptr;  // device staging for host outputs
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    void* det_mid = nullptr;    // dedispersed voltages of the two-step detect (plans / scrunch factors without a fused tail)
+    size_t det_mid_bytes = 0;
     int64_t owned_bytes = 0;
     // 7-smooth lengths (mixed_kernels.hpp): N = N1 * N2, N2 = 2^k rows of the power-of-two engine, N1 = P * Q any 7-smooth
     // number with P, Q <= kMixMaxLen; both column roles run k_colmix (mixP: the P-point stage, mixQ: the Q-point pass)
@@ -2128,7 +2130,7 @@ int pbh_plan_destroy(pbh_plan* p) {
     if (p->sub) pbh_plan_destroy(p->sub);
     if (p->cfilt) pbh_plan_destroy(p->cfilt);
     if (p->cf_in) (void)hipFree(p->cf_in);
-    void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->det_part, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out,
+    void* ptrs[] = {p->chirp_phase, p->work, p->work2, p->det_part, p->chirp, p->tw16k, p->tw_hi, p->tw_lo, p->chan_freq, p->mix_ft, p->stage_in, p->stage_out, p->det_mid,
                     p->bs_b, p->bs_a, p->bs_conv, p->mixP.wl, p->mixP.perm, p->mixQ.wl, p->mixQ.perm, p->mixR.wl, p->mixR.perm};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -3038,16 +3040,11 @@ int pbh_dedisperse_detect(pbh_plan* p, const void* in_c64, void* out_f32, int ns
         auto steps = build_steps(p, din, nullptr, tail);
         PBHCHECK(run_steps(steps, p->stream));
     } else if (nout > 0) {
-        // unfused form: dedisperse into a device buffer, then detect + scrunch
-        void* mid = nullptr;
-        PBHCHECK(dev_alloc(nullptr, &mid, mid_bytes));
-        auto steps = build_steps(p, din, (cf*)mid);
-        int rc = run_steps(steps, p->stream);
-        if (rc == PBH_OK)
-            rc = launch_detect(p->stream, (const cf*)mid, (real*)dout, nout, p->nchan, p->npol, mode, nscrunch);
-        if (hipStreamSynchronize(p->stream) != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, "detect: stream synchronisation failed");
-        (void)hipFree(mid);
-        PBHCHECK(rc);
+        // two-step form: dedisperse into a buffer the plan keeps, then detect + scrunch
+        PBHCHECK(ensure_stage(p, &p->det_mid, &p->det_mid_bytes, mid_bytes));
+        auto steps = build_steps(p, din, (cf*)p->det_mid);
+        PBHCHECK(run_steps(steps, p->stream));
+        PBHCHECK(launch_detect(p->stream, (const cf*)p->det_mid, (real*)dout, nout, p->nchan, p->npol, mode, nscrunch));
     }
     if (out_loc == PBH_HOST && out_bytes)
         HIPCHECK(xfer_d2h(out_f32, dout, out_bytes, p->stream));
