@@ -537,12 +537,19 @@ class Plan:
         self._stream_tail = (int(nscrunch), {0: (self.nchan, self.npol), 1: (self.nchan,), 2: (self.nchan, 4), 3: (self.nchan, 4)}[m])
         return self._stream_tail[1]
 
-    def _stream_out(self, nchunk, sample_shape):
-        """Host array a streaming call fills: voltages, or the detected rows stream_detect asked for."""
+    def _stream_out(self, nchunk, sample_shape, out=None):
+        """Host array a streaming call fills: voltages, or the detected rows stream_detect asked for (a caller's array is
+        checked against that)."""
         tail = getattr(self, "_stream_tail", None)
         if tail is None:
-            return np.empty((nchunk * self.nout,) + tuple(sample_shape), dtype=self.dtype)
-        return np.empty((nchunk * (self.nout // tail[0]),) + tail[1], dtype=self.real_dtype)
+            shape, dtype = (nchunk * self.nout,) + tuple(sample_shape), self.dtype
+        else:
+            shape, dtype = (nchunk * (self.nout // tail[0]),) + tail[1], self.real_dtype
+        if out is None:
+            return np.empty(shape, dtype=dtype)
+        if not isinstance(out, np.ndarray) or out.dtype != dtype or not out.flags.c_contiguous or out.size != int(np.prod(shape)):
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} numpy array of {int(np.prod(shape))} elements {shape}")
+        return out
 
     def dedisperse_stream(self, x_host, out=None):
         """Overlap-save over a long host block: (total, nchan, npol) c64 -> (nchunk*hop, ...), plus ms."""
@@ -554,8 +561,7 @@ class Plan:
         if hop <= 0 or x_host.shape[0] < self.nsample:
             raise ValueError("empty valid region or input shorter than one chunk")
         nchunk = (x_host.shape[0] - self.nsample) // hop + 1
-        if out is None:
-            out = self._stream_out(nchunk, x_host.shape[1:])
+        out = self._stream_out(nchunk, x_host.shape[1:], out)
         self._sync_stream()
         n, ms = C.c_int64(), C.c_float()
         _check(lib().pbh_dedisperse_stream(self._h, C.c_void_p(x_host.ctypes.data), int(x_host.shape[0]),
@@ -585,8 +591,7 @@ class Plan:
         if hop <= 0 or total_nsample < self.nsample:
             raise ValueError("empty valid region or input shorter than one chunk")
         nchunk = (int(total_nsample) - self.nsample) // hop + 1
-        if out is None:
-            out = self._stream_out(nchunk, (self.nchan, self.npol))
+        out = self._stream_out(nchunk, (self.nchan, self.npol), out)
         lay = _RawLayout(**{k: int(v) for k, v in layout.items()})
         mask = None
         if conj is not None:
