@@ -242,6 +242,13 @@ class TestHotPathWithoutGpu:
         with pytest.raises(TypeError):
             pb.DM(1.0).chirp_from_signal(pb.Signal(x, sample_rate=1 * u.MHz))
 
+    def test_detected_stream_arguments_before_gpu(self):
+        """A filterbank stream needs a scrunch factor a fused detect tail exists for: said before anything touches the GPU."""
+        z = pb.DualPolarizationSignal(rnd((4096, 2, 2)), sample_rate=1 * u.MHz, center_freq=1 * u.GHz, pol_type="linear")
+        for bad in (3, 48, 100):
+            with pytest.raises(ValueError, match="nscrunch"):
+                pb.coherent_dedispersion_stream(z, pb.DM(1.0), chunk=1024, detect="I", nscrunch=bad)
+
     def test_product_does_not_import_oracle(self):
         import os, re
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
