@@ -251,8 +251,8 @@ int pbh_dedisperse_detect_layout(pbh_plan* plan, const void* in_dev, int in_layo
  * them, and for |z|^2 / Stokes I at nsample = 2^20 ... 2^24 (64- to 1024-row column tiles, nscrunch a divisor of 2^14) the inverse
  * column pass itself does (4 KiB of partial sums per tile instead of 128 KiB of voltages; PBH_DETECT_COLQ=0 to
  * compare).  The plan then holds S * nsample / 16 floats of partial sums beside its workspace.  With nscrunch == 1
- * (to_intensity / to_stokes at full time resolution) the last layout pass of a power-of-two plan with 2 ... 128
- * series (a power of two) writes the detected rows instead of the voltages (PBH_DETECT_REINT=0 to compare).      */
+ * (to_intensity / to_stokes at full time resolution) the last layout pass of a multi-pass plan with an even
+ * number of series writes the detected rows instead of the voltages (PBH_DETECT_REINT=0 to compare).             */
 int pbh_dedisperse_detect(pbh_plan* plan, const void* in_c64, void* out_f32, int nscrunch, int mode,
                           int in_loc, int out_loc);
 

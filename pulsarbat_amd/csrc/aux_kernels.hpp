@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void k_deint_blk(const cf* __restrict__ in, cf
 }
 
 // planar [s][t] -> (stop-start, S) interleaved, keeping t in [start, stop)
-template <int SB, int TB>
+// DET >= 0 (float32 build): the pass detects instead (see k_reinterleave_p2): a lane's two series are a polarisation pair
+template <int SB, int TB, int DET = -1>
 __global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf* __restrict__ out, int64_t start,
                                                    int64_t stop, int S, int64_t plane) {
     constexpr int VE = 16 / (int)sizeof(cf);
@@ -248,6 +249,21 @@ __global__ __launch_bounds__(256) void k_reint_blk(const cf* __restrict__ in, cf
             union { vec16 v; cf c[VE]; } x;
 #pragma unroll
             for (int e = 0; e < VE; ++e) x.c[e] = lds[(sv * VE + e) * LD + t];
+            if constexpr (DET >= 0) {
+                real* ro = reinterpret_cast<real*>(out);
+                const int64_t r = t0 - start + t;
+                const cf a = x.c[0], b = x.c[VE - 1];
+                const real aa = a.x * a.x + a.y * a.y, bb = b.x * b.x + b.y * b.y;
+                if constexpr (DET == 0) {
+                    *reinterpret_cast<float2*>(ro + r * S + s) = make_float2(aa, bb);
+                } else if constexpr (DET == 1) {
+                    ro[r * (S / 2) + s / 2] = aa + bb;
+                } else {
+                    const real re2 = 2 * (a.x * b.x + a.y * b.y), im2 = 2 * (a.x * b.y - a.y * b.x);   // 2 conj(a) b
+                    *reinterpret_cast<float4*>(ro + (r * (S / 2) + s / 2) * 4) =
+                        DET == 2 ? make_float4(aa + bb, aa - bb, re2, im2) : make_float4(aa + bb, re2, im2, aa - bb);
+                }
+            } else
             *reinterpret_cast<vec16*>(out + (t0 - start + t) * S + s) = x.v;
         }
     }

@@ -685,20 +685,43 @@ static int launch_reinterleave(const cf* work, cf* out, int64_t start, int64_t s
 // The final layout pass as a DETECTING pass at full time resolution (k_reinterleave_p2<.., DET>): float32 to_intensity /
 // to_stokes of the cropped samples straight from the planar workspace.  Whole tiles through the tile kernel, the last rows
 // through k_detect_planar (one output per wavefront: fine for fewer rows than a tile).
-static bool reint_detect_ok(int S, int npol, int mode) {
+static bool reint_detect_ok(int S, int npol, int mode, int64_t N) {
 #ifdef PBH_F64
-    (void)S; (void)npol; (void)mode;
+    (void)S; (void)npol; (void)mode; (void)N;
     return false;
 #else
     static const bool on = [] { const char* e = getenv("PBH_DETECT_REINT"); return e ? atoi(e) != 0 : true; }();
-    if (!on || (S & (S - 1)) != 0 || S < 2 || S > 128) return false;
+    // power-of-two counts up to 128: k_reinterleave_p2; many series and other even counts: k_reint_blk
+    if (!on || !(((S & (S - 1)) == 0 && S >= 2 && S <= 128) || blk_series(S, N) != 0)) return false;
     return mode == PBH_DETECT_INTENSITY || npol == 2;
 #endif
 }
+#ifndef PBH_F64
+template <int SB>
+static int launch_reint_blk_detect(const cf* work, real* out, int64_t start, int64_t stop, int S, int mode, int64_t plane, hipStream_t st) {
+    constexpr int TB = kBlkElems / SB;
+    const dim3 grid((unsigned)((stop - start + TB - 1) / TB), (unsigned)((S + SB - 1) / SB));
+    cf* o = reinterpret_cast<cf*>(out);
+    if (mode == 0) hipLaunchKernelGGL((k_reint_blk<SB, TB, 0>), grid, dim3(256), 0, st, work, o, start, stop, S, plane);
+    else if (mode == 1) hipLaunchKernelGGL((k_reint_blk<SB, TB, 1>), grid, dim3(256), 0, st, work, o, start, stop, S, plane);
+    else if (mode == 2) hipLaunchKernelGGL((k_reint_blk<SB, TB, 2>), grid, dim3(256), 0, st, work, o, start, stop, S, plane);
+    else hipLaunchKernelGGL((k_reint_blk<SB, TB, 3>), grid, dim3(256), 0, st, work, o, start, stop, S, plane);
+    HIPCHECK(hipGetLastError());
+    return PBH_OK;
+}
+#endif
 static int launch_reint_detect(const cf* work, real* out, int64_t start, int64_t stop, int S, int nchan, int npol, int mode, int64_t plane,
                                hipStream_t st) {
     if (stop <= start) return PBH_OK;
 #ifndef PBH_F64
+    switch (blk_series(S, plane)) {   // many series, or an even count that is not a power of two: two-axis tiles, edges included
+        case 4: return launch_reint_blk_detect<4>(work, out, start, stop, S, mode, plane, st);
+        case 8: return launch_reint_blk_detect<8>(work, out, start, stop, S, mode, plane, st);
+        case 16: return launch_reint_blk_detect<16>(work, out, start, stop, S, mode, plane, st);
+        case 32: return launch_reint_blk_detect<32>(work, out, start, stop, S, mode, plane, st);
+        case 64: return launch_reint_blk_detect<64>(work, out, start, stop, S, mode, plane, st);
+    }
+    if ((S & (S - 1)) != 0 || S > 128) return fail(PBH_ERR_STATE, "detecting layout pass: no tile kernel for this series count");
     const int TN = tr_rows(S);
     const int64_t full = (stop - start) / TN;
     if (full > 0) {
@@ -1133,7 +1156,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
                 steps.push_back({"k_radix_inv", [=](hipStream_t st) { return launch_colmix<+1>(a, st); }});
             }
         }
-        if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode)) {
+        if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode, N)) {
             const int nchan = p->nchan, npol = p->npol, mode = tail.mode;
             real* dout = tail.out;
             steps.push_back({"k_reint_detect", [=](hipStream_t st) {
@@ -1366,7 +1389,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             }
         }
         if (det_done) {
-        } else if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode)) {
+        } else if (tail.out && tail.nscrunch == 1 && reint_detect_ok(S, p->npol, tail.mode, N)) {
             const int nchan = p->nchan, npol = p->npol, mode = tail.mode;
             real* dout = tail.out;
             steps.push_back({"k_reint_detect", [=](hipStream_t st) {
@@ -1431,7 +1454,7 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
     if (!(p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && p->nchan <= 65535)) return false;
     if (nscrunch % 64 == 0) return true;
     // full time resolution: the last layout pass of the planar pipelines (2^k, m 2^k and 7-smooth lengths) detects (launch_reint_detect)
-    return nscrunch == 1 && !p->bsL && reint_detect_ok(p->S, p->npol, mode);
+    return nscrunch == 1 && !p->bsL && reint_detect_ok(p->S, p->npol, mode, p->N);
 }
 
 static int run_steps(std::vector<Step>& steps, hipStream_t st) {

@@ -695,11 +695,14 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
                                         ((1 << 18, 3, 2), "I"),
                                         ((3 << 17, 2, 2), "linear"), ((400000, 2, 2), "I"), ((64800, 4, 2), "intensity"),   # m 2^k, 7-smooth
                                         ((20000, 8, 2), "circular"), ((52488, 2, 2), "I"),                                 # ... one level; mixed rows
-                                        ((1 << 18, 16, 2), "I"), ((1 << 17, 32, 2), "circular"), ((1 << 18, 32), "intensity")])
+                                        ((1 << 18, 16, 2), "I"), ((1 << 17, 32, 2), "circular"), ((1 << 18, 32), "intensity"),
+                                        ((1 << 16, 128, 2), "I"), ((1 << 15, 256, 2), "linear"), ((1 << 17, 12, 2), "circular"),   # two-axis tiles
+                                        ((1 << 17, 100), "intensity")])
 def test_detect_in_the_last_layout_pass(shape, mode):
     """nscrunch = 1: to_intensity / to_stokes of the dedispersed voltages at full time resolution, computed by the last layout
     pass from the planar workspace (k_reinterleave_p2<.., DET>; the rows beyond the last whole tile by k_detect_planar) -- the
-    voltages are never stored.  (3 channels x 2 pols is not a power-of-two series count: the two-step form.)"""
+    voltages are never stored.  Many series and even counts that are no power of two: the two-axis tile kernel (k_reint_blk<..,
+    DET>)."""
     dm, sr, fc = 12.0, 1e6, 1e9
     x = orc.synthetic_block(shape, 33)
     z = make_signal(x, sr, fc)

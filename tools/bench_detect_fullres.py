@@ -11,7 +11,7 @@ from pulsarbat_amd import _hip
 from pulsarbat_amd.device import DeviceArray
 sys.path.insert(0, "tools")
 from bench_configs import crop
-n, nchan, npol, dm, band, center = 1 << 24, 8, 2, 56.77, 400e6, 1.4e9
+n, nchan, npol, dm, band, center = 1 << LOG2N, NCHAN, 2, 56.77, 400e6, 1.4e9
 sr = band / nchan
 start, stop = crop(dm, n, band, center, sr)
 freqs = center + sr * (np.arange(nchan) + 0.5 - nchan / 2)
@@ -39,6 +39,8 @@ torch.cuda.synchronize()
 res["voltages only"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
 print(json.dumps(res))
 '''
+# usage: python tools/bench_detect_fullres.py [log2n=24] [nchan=8]    (17 1024: a channelised block, two-axis layout tiles)
+CHILD = CHILD.replace("LOG2N", sys.argv[1] if len(sys.argv) > 1 else "24").replace("NCHAN", sys.argv[2] if len(sys.argv) > 2 else "8")
 for flag in ("1", "0"):
     env = dict(os.environ, PBH_DETECT_REINT=flag)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
