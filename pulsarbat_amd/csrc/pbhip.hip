@@ -1047,7 +1047,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         }});
         return steps;
     }
-    if (p->N1 == 1 && p->work && single_planar_ok(p) && !tail.out && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR &&
+    if (p->N1 == 1 && p->work && single_planar_ok(p) && io.in_layout == PBH_LAYOUT_SAMPLE_MAJOR &&
         io.out_layout == PBH_LAYOUT_SAMPLE_MAJOR) {
         // One-tile blocks with many series (what a channeliser with long segments hands over: 2^14 samples x thousands of
         // narrow channels).  k_small would read 8-byte pieces of every 128-byte input line once per series; here the two
@@ -1065,6 +1065,25 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         RowParams rp{work, p->chirp, p->tw16k, (int64_t)S, 1, p->npol, 0, ctr0 + 2};
         rp.cdiv = FR > 1 ? p->npol : 1;
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(M, rp, st); }});
+        if (tail.out) {   // detect tail (can_fuse_detect): the planar copy holds the dedispersed rows in time order
+            const int nchan = p->nchan, npol = p->npol, mode = tail.mode, ns = tail.nscrunch;
+            real* dout = tail.out;
+            if (ns == 1) {
+                steps.push_back({"k_reint_detect", [=](hipStream_t st) {
+                    return launch_reint_detect(work, dout, start, stop, S, nchan, npol, mode, N, st);
+                }});
+            } else {
+                const int64_t nout = (stop - start) / ns;
+                steps.push_back({"k_detect_planar", [=](hipStream_t st) {
+                    if (nout <= 0) return (int)PBH_OK;
+                    hipLaunchKernelGGL(k_detect_planar, dim3((unsigned)((nout + 3) / 4), (unsigned)nchan), dim3(256), 0, st,
+                                       (const cf*)work, dout, N, start, nout, nchan, npol, mode, ns);
+                    HIPCHECK(hipGetLastError());
+                    return (int)PBH_OK;
+                }});
+            }
+            return steps;
+        }
         const int64_t orow = io.out_row_elems;
         const auto pp = io.part_ptr;
         const auto pr = io.part_row;
@@ -1451,7 +1470,9 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 }
 
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
-    if (!(p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5 && p->nchan <= 65535)) return false;
+    // multi-pass planar plans, and one-tile plans that run layout pass + planar rows + layout pass (many series)
+    const bool planar = (p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5) || (p->N1 == 1 && p->work && !p->bsL && single_planar_ok(p));
+    if (!planar || p->nchan > 65535) return false;
     if (nscrunch % 64 == 0) return true;
     // full time resolution: the last layout pass of the planar pipelines (2^k, m 2^k and 7-smooth lengths) detects (launch_reint_detect)
     return nscrunch == 1 && !p->bsL && reint_detect_ok(p->S, p->npol, mode, p->N);

@@ -348,6 +348,21 @@ def test_full_size_properties():
     assert e < RTOL_L2, f"series ({c},{p}) relative L2 {e:.2e}"
 
 
+def test_detect_scrunch_one_tile_many_series():
+    """One-tile plans with many series (layout pass + planar rows + layout pass): the scrunching detect tail reads the planar
+    copy, the voltages are not stored."""
+    shape, dm, sr, fc = (1 << 14, 128, 2), 2.0, 1e6, 1e9
+    x = orc.synthetic_block(shape, 15)
+    z = make_signal(x, sr, fc)
+    yr, s0, _ = orc.coherent_dedispersion(x, dm, sr, fc)
+    for mode, k in (("I", 64), ("linear", 128)):
+        got, start = pb.dedisperse_detect(z.to_device(), pb.DM(dm), mode=mode, nscrunch=k)
+        want = orc.scrunch(orc.to_stokes(yr, "linear")[:, :, 0] if mode == "I" else orc.to_stokes(yr, mode), k)
+        got = np.asarray(got)
+        assert start == s0 and got.shape == want.shape
+        assert np.abs(got - want).max() < 3e-5 * np.abs(want).max() * max(1.0, np.sqrt(k) / 4)
+
+
 @pytest.mark.parametrize("mode,k", [("I", 1024), ("linear", 256), ("circular", 64), ("intensity", 128),
                                     ("I", 48), ("linear", 1)])
 def test_detect_scrunch_modes(mode, k):
@@ -697,7 +712,8 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
                                         ((20000, 8, 2), "circular"), ((52488, 2, 2), "I"),                                 # ... one level; mixed rows
                                         ((1 << 18, 16, 2), "I"), ((1 << 17, 32, 2), "circular"), ((1 << 18, 32), "intensity"),
                                         ((1 << 16, 128, 2), "I"), ((1 << 15, 256, 2), "linear"), ((1 << 17, 12, 2), "circular"),   # two-axis tiles
-                                        ((1 << 17, 100), "intensity")])
+                                        ((1 << 17, 100), "intensity"),
+                                        ((1 << 14, 128, 2), "I"), ((1 << 14, 128), "intensity")])   # one-tile plans with many series
 def test_detect_in_the_last_layout_pass(shape, mode):
     """nscrunch = 1: to_intensity / to_stokes of the dedispersed voltages at full time resolution, computed by the last layout
     pass from the planar workspace (k_reinterleave_p2<.., DET>; the rows beyond the last whole tile by k_detect_planar) -- the
