@@ -368,7 +368,7 @@ def main():
     alg = {"k_col_fwd": 16.0, "k_row_fused": 16.0 + 8.0 / NPOL, "k_col_inv": 8.0 + 8.0 * crop_frac,
            "k_deinterleave": 16.0, "k_reinterleave": 16.0 * crop_frac, "k_small": 8.0 + 8.0 * crop_frac + 8.0 / NPOL}
     dom_name, dom_ms = max(kern, key=lambda kv: kv[1])
-    dom_bytes = alg[dom_name] * samples_gpu
+    dom_bytes = alg.get(dom_name, 16.0) * samples_gpu   # an unlisted pass (k_radix_*, k_pad ...) moves 8 r + 8 w
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -387,16 +387,31 @@ def main():
     # what the five passes really move, and what that costs at the chip's own copy rate, measured now
     moved = {"k_deinterleave": 16.0, "k_col_fwd": 16.0, "k_row_fused": 16.0 + 4.0 / NPOL, "k_col_inv": 8.0 + 8.0 * crop_frac,
              "k_reinterleave": 16.0 * crop_frac, "k_small": 8.0 + 8.0 * crop_frac + 8.0 / NPOL}
-    moved_bytes = sum(moved[k] for k, _ in kern) * samples_gpu
-    copy_ms = _hip.copy_bench(1 << 31, iters=10, device=local_rank)
-    copy_gbps = 2.0 * (1 << 31) / copy_ms / 1e6
+    # optional figures: a plan with a pass this table does not know (k_radix_*, k_pad, k_bs_* at other sizes) loses the floor, not the line
+    known = all(k in moved for k, _ in kern)
+    moved_bytes = sum(moved[k] for k, _ in kern) * samples_gpu if known else None
     path = {"alg_bytes_per_sample": info["alg_bytes_per_sample"],
             "achieved": path_bytes / (total_kernel_ms * 1e-3) / 1e9, "unit": "GB/s",
             "frac": path_bytes / (total_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "kernel_ms": {k: round(v, 4) for k, v in kern}, "kernel_ms_total": total_kernel_ms,
-            "moved_bytes_per_step": moved_bytes, "copy_ceiling_GBps": copy_gbps,
-            "floor_ms": moved_bytes / copy_gbps / 1e6,
-            "floor_note": "bytes the five passes move / the float4 device copy rate measured in this run (pbh_copy_bench, 2 GiB)"}
+            "moved_bytes_per_step": moved_bytes}
+    try:
+        # the chip's own streaming rates, measured now (pbh_stream_bench, 2 GiB): a copy between two buffers, and a
+        # read-modify-write of one buffer in place (what the three middle passes do to the planar work buffer)
+        copy_ms = _hip.stream_bench(1 << 31, iters=10, device=local_rank, mode="copy")
+        rmw_ms = _hip.stream_bench(1 << 31, iters=10, device=local_rank, mode="rmw")
+        copy_gbps = 2.0 * (1 << 31) / copy_ms / 1e6
+        rmw_gbps = 2.0 * (1 << 31) / rmw_ms / 1e6
+        path.update({"copy_ceiling_GBps": copy_gbps, "rmw_ceiling_GBps": rmw_gbps})
+        if known:
+            inplace = {"k_col_fwd", "k_row_fused", "k_col_inv"}
+            b_in = sum(moved[k] for k, _ in kern if k in inplace) * samples_gpu
+            path.update({"floor_ms": moved_bytes / copy_gbps / 1e6,
+                         "floor_ms_rmw": (moved_bytes - b_in) / copy_gbps / 1e6 + b_in / rmw_gbps / 1e6,
+                         "floor_note": "floor_ms: bytes the passes move / the float4 copy rate of this run; floor_ms_rmw: the "
+                                       "in-place passes' bytes priced at the in-place read-modify-write rate instead"})
+    except Exception as exc:
+        path["ceiling_error"] = repr(exc)
 
     result = None
     if rank == 0:

@@ -101,6 +101,15 @@ int pbh_plan_set_stream(pbh_plan* plan, void* hip_stream);
 int pbh_plan_set_variant(pbh_plan* plan, int variant);
 int pbh_plan_info(const pbh_plan* plan, pbh_plan_info_t* info);
 
+/* Placement aid (no reference counterpart; measurement-driven).  On MI355X every large device allocation belongs
+ * to one of two "classes", and a pass that streams from one allocation into another is ~5 % faster when their classes
+ * differ.  The plan keeps its two work buffers of opposite class and orders its passes around the caller's buffers; a host
+ * that can choose WHERE its input and output live (bench.py does) asks here: *cls = 0 when the `bytes` at `dev_ptr` are of
+ * the class of the plan's first work buffer, 1 when of the other, -1 when that cannot be told (buffers under 1 GiB, plans
+ * that run in one work buffer).  The fastest arrangement gives input and output the SAME class.  Costs one timed 1-GiB device
+ * copy (reads dev_ptr, writes plan scratch) the first time a pointer is seen; synchronises the plan's stream.             */
+int pbh_plan_buffer_class(pbh_plan* plan, const void* dev_ptr, int64_t bytes, int* cls);
+
 /* ---- chirp (transfer function) ------------------------------------------------------------- */
 /* Replaces _transfer_function for every channel of a signal, i.e. DispersionMeasure.
  * chirp_from_signal (dedispersion.py:19-23, 59-75): float64 phase
@@ -388,6 +397,10 @@ int pbh_real_to_complex(int device, void* hip_stream, const void* in_dev, void* 
 
 /* Device-to-device streaming copy of `bytes` (float4 per lane): the achievable-HBM reference number. */
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean);
+/* The same yardstick with a mode: 0 = copy between two buffers of `bytes` (= pbh_copy_bench), 1 = read-modify-write of ONE
+ * buffer in place -- the ceiling of the three middle passes of pbh_dedisperse, which update the planar work buffer where it
+ * stands (no reference counterpart: measurement support for bench.py's path_roofline).                                  */
+int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_mean);
 
 #ifdef __cplusplus
 }

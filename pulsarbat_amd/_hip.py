@@ -15,7 +15,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["HipError", "HipUnavailableError", "lib", "available", "Plan", "detect", "decode", "trim", "relayout", "fft_c2c",
-           "chirp_function", "copy_bench"]
+           "chirp_function", "copy_bench", "stream_bench"]
 
 HOST, DEVICE = 0, 1
 DTYPES = {np.dtype(np.complex64): 0, np.dtype(np.complex128): 1}   # pbh_dtype
@@ -66,6 +66,7 @@ SIGNATURES = {
     "pbh_plan_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbh_plan_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "pbh_plan_info": (C.c_int, [C.c_void_p, C.POINTER(_PlanInfo)]),
+    "pbh_plan_buffer_class": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int)]),
     "pbh_chirp_generate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double]),
     "pbh_chirp_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "pbh_chirp_upload_as": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -124,6 +125,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "pbh_real_to_complex": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pbh_copy_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    "pbh_stream_bench": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None
@@ -307,6 +309,36 @@ class Plan:
     def nout(self):
         return self.crop_stop - self.crop_start
 
+    def _empty_like_class(self, oshape, x):
+        """Output array of the input's allocation class where that can be told and arranged (pbh_plan_buffer_class: the
+        passes then all stream between allocations of different class).  Candidates of the wrong class are kept alive
+        while the next one is allocated, so that the allocator hands out a different block, and go back to its cache."""
+        from .device import DeviceArray
+        out = DeviceArray.empty(oshape, self.dtype, device=self.device)
+        if self.dtype != np.complex64 or int(np.prod(oshape)) * 8 < (1 << 30):
+            return out
+        want = self.buffer_class(x)
+        if want < 0:
+            return out
+        held = []
+        for _ in range(3):
+            if self.buffer_class(out) in (want, -1):
+                break
+            held.append(out)
+            out = DeviceArray.empty(oshape, self.dtype, device=self.device)
+        del held
+        return out
+
+    def buffer_class(self, x):
+        """Allocation class of a device array relative to the plan's work buffer (pbh_plan_buffer_class): 0, 1, or -1 when
+        it cannot be told.  Streaming passes are ~5 % faster between allocations of different class; give the input and the
+        output of a repeated call the same class (bench.py allocates its output that way)."""
+        self._sync_stream()
+        cls = C.c_int(-1)
+        nbytes = int(np.prod(x.shape)) * np.dtype(x.dtype).itemsize
+        _check(lib().pbh_plan_buffer_class(self._h, C.c_void_p(x.data_ptr()), nbytes, C.byref(cls)))
+        return int(cls.value)
+
     def chirp_generate(self, coeff_hz, dt_s, chan_freq_hz, ref_freq_hz):
         self._sync_stream()
         freqs = np.ascontiguousarray(chan_freq_hz, dtype=np.float64)
@@ -382,7 +414,7 @@ class Plan:
                     out = DeviceArray.empty_series_major(oshape, self.dtype, device=self.device, align_start=self.crop_start)
                     out_pitch = out.series_major_pitch()
                 else:
-                    out = DeviceArray.empty(oshape, self.dtype, device=self.device)
+                    out = self._empty_like_class(oshape, x) if in_pitch is None else DeviceArray.empty(oshape, self.dtype, device=self.device)
                     out_pitch = None
             if in_pitch is not None or out_pitch is not None:
                 if tuple(out.shape) != oshape or out.dtype != self.dtype:
@@ -393,7 +425,7 @@ class Plan:
                 return out
         if out is None:
             if isinstance(x, DeviceArray):
-                out = DeviceArray.empty(oshape, self.dtype, device=self.device)
+                out = self._empty_like_class(oshape, x)
             else:
                 out = np.empty(oshape, dtype=self.dtype)
         pin, lin = _ptr_loc(x)
@@ -846,4 +878,13 @@ def copy_bench(nbytes, iters=10, device=0):
     _require_device()
     ms = C.c_float()
     _check(lib().pbh_copy_bench(int(device), int(nbytes), int(iters), C.byref(ms)))
+    return float(ms.value)
+
+
+def stream_bench(nbytes, iters=10, device=0, mode="copy"):
+    """Mean ms per launch of the streaming yardstick: ``copy`` (two buffers) or ``rmw`` (one buffer, read-modify-write in
+    place: what the three middle passes do to the planar work buffer)."""
+    _require_device()
+    ms = C.c_float()
+    _check(lib().pbh_stream_bench(int(device), int(nbytes), int(iters), {"copy": 0, "rmw": 1}[mode], C.byref(ms)))
     return float(ms.value)

@@ -548,6 +548,23 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     x.y = __float_as_uint(a.y);
     __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, PBH_STORE_AUX);
 }
+// Two complex64 values as ONE 16-byte store.  The same gfx950 hazard as the complex128 store above applies: met again in
+// round 4 in k_rowq16, where hipcc computed the last butterfly's sums into the registers of the previous store
+// (`buffer_store_dwordx4 v[70:73], v84, s[16:19], s44 offen` / `v_add_f32 v70, ...`): lanes 12-15 of every 16 stored the NEXT
+// pair's first value.  The wait states ride on every 16-byte store; tests/test_abi.py scans the built code object for the
+// pattern (tools/isa_hazards.py) so that a store added without them fails on the CPU box.
+__device__ __forceinline__ void buf_store_pair(rsrc_t r, int voff, int soff, cf a, cf b) {
+    u32x4 x;
+    x.x = __float_as_uint(a.x);
+    x.y = __float_as_uint(a.y);
+    x.z = __float_as_uint(b.x);
+    x.w = __float_as_uint(b.y);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 #endif
 
 // ---- float64 inter-pass twiddles W_N^p via a two-level table ------------------------------------

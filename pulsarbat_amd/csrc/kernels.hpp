@@ -850,11 +850,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowp16(RowpParams p) {
         a = make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
         b = make_cf(__uint_as_float(x.z), __uint_as_float(x.w));
     };
-    auto store_pair = [&](rsrc_t r, int j, cf a, cf b) {
-        u32x4 x;
-        x.x = __float_as_uint(a.x); x.y = __float_as_uint(a.y); x.z = __float_as_uint(b.x); x.w = __float_as_uint(b.y);
-        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff16, j * STEP16, 0);
-    };
+    auto store_pair = [&](rsrc_t r, int j, cf a, cf b) { buf_store_pair(r, voff16, j * STEP16, a, b); };   // (hazard wait states: fft_core.hpp)
 
     uint32_t u = blockIdx.x;
     if (u >= npair) return;

@@ -46,6 +46,8 @@
 #define pbh_fft_c2c PBH_FN(fft_c2c)
 #define pbh_plan_profile PBH_FN(plan_profile)
 #define pbh_copy_bench PBH_FN(copy_bench)
+#define pbh_stream_bench PBH_FN(stream_bench)
+#define pbh_plan_buffer_class PBH_FN(plan_buffer_class)
 #include "../../include/pbhip.h"
 
 #include <hip/hip_runtime.h>
@@ -56,11 +58,13 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "aux_kernels.hpp"
 #include "kernels.hpp"
 #include "mixed_kernels.hpp"
+#include "fd4_kernels.hpp"
 
 using namespace PBH_NS;
 
@@ -229,6 +233,21 @@ struct pbh_plan {
 
     cf* work = nullptr;      // planar workspace, S * N
     cf* work2 = nullptr;     // second planar workspace: the middle passes of the power-of-two planar pipeline ping-pong (oop_ok)
+    // Allocation "classes" (pair_class below): a pass streaming from one large allocation into another runs ~5 % faster
+    // when the two are of different class.  work2 is chosen of the class opposite to work's when it is allocated;
+    // t_same / t_diff are the probe copy's times for a same-class and a different-class pair, the cache remembers what
+    // the caller's buffers turned out to be (0 = work's class, 1 = the other, -1 = not decidable).
+    float cls_t_same = 0.f, cls_t_diff = 0.f;
+    size_t cls_len = 0;
+    struct ClsEntry { const void* ptr = nullptr; size_t bytes = 0; int cls = -1; };
+    ClsEntry cls_cache[8];
+    int cls_next = 0;
+    // four-pass schedule: which of the two work buffers holds the Q4 intermediate, per (input, output) pair -- decided by
+    // timing both assignments on the first call with that pair (fd4_roles)
+    struct RoleEntry { const void* in = nullptr; const void* out = nullptr; int swap = 0; };
+    RoleEntry role_cache[8];
+    int role_next = 0;
+    int fd4_force = -1;   // >= 0 while fd4_roles times an assignment
     real* det_part = nullptr;  // detect tail fused into the inverse column pass: per-tile power sums (ColpParams::det_part),
     size_t det_bytes = 0;      // S * N / 16 floats + S * N1 * (N2 / nscrunch) for the groups with a scrunch boundary
     cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
@@ -542,6 +561,58 @@ static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
 }
 #endif
 
+#ifndef PBH_F64
+// ---- four-pass schedule (fd4_kernels.hpp) -------------------------------------------------------------------------------
+// PBH_FD4: 0 = never, 1 = where the geometry allows it (default), see fd4_ok
+static int fd4_mode() {   // (read at every call: the tests switch it inside one process)
+    const char* e = getenv("PBH_FD4");
+    return e ? atoi(e) : 1;
+}
+// PBH_FD4_SP=<c><r>: pacing variant of the column (tens) and row (units) kernels (A/B runs)
+static int fd4_sp() {
+    const char* e = getenv("PBH_FD4_SP");
+    return e ? atoi(e) : 0;
+}
+// grid of a gang-scheduled kernel: a multiple of 8 * members (blocks b, b + 8, ... share an XCD), one workgroup per CU
+static int gang_grid(int members, int64_t units) {
+    int g = row_grid();
+    if (g >= 8 * members) g -= g % (8 * members);
+    else g -= g % members;
+    if (g < members) g = members;
+    if ((int64_t)(g / members) > units) g = (int)units * members;
+    return g;
+}
+static int launch_colfd(int M, const ColfdParams& prm, hipStream_t st) {
+    const int NQ = prm.S / 4, C = (kTilePoints / M) / 4;
+    const int grid = gang_grid(NQ, prm.N2 / C);
+    const int sp = fd4_sp() / 10;
+    switch (M) {
+#define X(m) case m: return sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                                    : launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+        X(64) X(128) X(256) X(512) X(1024)
+#undef X
+    }
+    return fail(PBH_ERR_UNSUPPORTED, "direct forward column pass: 64 ... 1024 rows");
+}
+static int launch_rowq(const RowqParams& prm, hipStream_t st) {
+    const int grid = gang_grid(4, (int64_t)(prm.S / 4) * prm.N1);
+    switch (fd4_sp() % 10) {   // A/B: loads of the next tile that ride in the forward transform (default 10 of 16)
+        case 1: return launch_tile_kernel(k_rowq16<PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+        case 2: return launch_tile_kernel(k_rowq16<PBH_R, 4>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+        case 3: return launch_tile_kernel(k_rowq16<PBH_R, 8>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+    }
+    return launch_tile_kernel(k_rowq16<PBH_R, 10>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
+}
+// geometry the four-pass schedule covers: quads of series, one row tile per row, 1024-row column tiles whose 2-GiB span of
+// the caller's block fits a buffer descriptor's 32-bit offsets
+static bool fd4_ok(const pbh_plan* p) {
+    if (fd4_mode() == 0 || !p->has_phase || !row_phase_enabled() || !p->phase16) return false;
+    if (p->P != 1 || p->N2 != kTilePoints || p->N1 < 64 || p->N1 > 1024 || !is_pow2(p->N1) || p->S % 4 != 0 || p->S < 4 || p->S > 16) return false;
+    const int64_t span = (((int64_t)(p->N1 - 1) * p->N2 + 3) * p->S + 4) * (int64_t)sizeof(cf);
+    return span < (1LL << 32) && (int64_t)31 * (p->N1 / PBH_R) * p->N2 * p->S * (int64_t)sizeof(cf) < (1LL << 31);
+}
+#endif
+
 static int launch_small(int M, const SmallParams& prm, hipStream_t st, int64_t nseg = 1) {
     const int F = kTilePoints / M;
     if (nseg < 1 || nseg > 65535) return fail(PBH_ERR_UNSUPPORTED, "segment count out of range for one launch");
@@ -841,6 +912,133 @@ static int oop_mode() {
     static const int m = [] { const char* e = getenv("PBH_OOP"); return e ? atoi(e) : 0; }();
     return m;
 }
+#ifndef PBH_F64
+// ---- allocation classes ---------------------------------------------------------------------------------------------------
+// Measured on MI355X (tools/micro/bufprobe.hip, profiles/r04_bufprobe.txt): every large hipMalloc allocation belongs to one of
+// two classes; a copy between allocations of the SAME class (or inside one allocation) takes 0.755 ms per 2 GiB, between
+// allocations of DIFFERENT class 0.72 ms, whatever the offsets inside them -- and the passes of this library follow: the
+// de-interleave pass 0.80 / 0.75 ms, the column passes out of place 0.86 / 0.82 and 0.756 / 0.72, the direct forward pass
+// 1.42 / 1.33.  That is the 2.5 % per-process spread of round 3: which classes the process's buffers happened to get.  The
+// class of an allocation cannot be asked for, but a pair can be probed: one timed copy between them against a copy inside the
+// plan's own work buffer (same class by definition).
+// Copies of `bytes` from a to b1 and from a to b2, alternating, REPS times each: the fastest of each (the first pair warms the
+// TLBs and does not count).  The two times come from the same moments of the same chip, which is what makes a 4-5 %
+// difference readable (single timings of a 1-GiB copy scatter by 2 %).
+static bool probe_copy_pair(const void* a, void* b1, void* b2, size_t bytes, hipStream_t st, float* t1, float* t2) {
+    const unsigned grid = (unsigned)(bytes / 16 / 1024);
+    *t1 = *t2 = -1.f;
+    if (grid == 0) return false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipGetLastError();
+        return false;
+    }
+    bool ok = true;
+    constexpr int REPS = 6;
+    for (int rep = 0; rep <= REPS && ok; ++rep) {
+        for (int which = 0; which < 2 && ok; ++which) {
+            (void)hipEventRecord(e0, st);
+            hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, st, (const float4*)a, (float4*)(which ? b2 : b1), (int64_t)grid * 1024);
+            (void)hipEventRecord(e1, st);
+            float ms = 0.f;
+            ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            float* t = which ? t2 : t1;
+            if (ok && rep > 0 && (*t < 0 || ms < *t)) *t = ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return ok && *t1 > 0 && *t2 > 0;
+}
+static bool class_probing() {   // PBH_CLASS=0: take allocations as they come (A/B runs)
+    const char* e = getenv("PBH_CLASS");
+    return e ? atoi(e) != 0 : true;
+}
+constexpr float kClassGap = 0.02f;   // relative difference of the two copies below which a probe decides nothing
+// second work buffer, of the class opposite to `work`'s where that can be arranged: up to six candidates are allocated and
+// held, full-size copies work -> candidate timed round robin (the fastest of five each), and the candidate with the fastest
+// copy kept -- "opposite" when it beats the slowest by 2.5 % (two groups exist among the candidates).  ~12 GiB are held for
+// the ~40 ms this takes; with PBH_CLASS=0, or for blocks under 512 MiB, the first allocation is taken as it comes.
+static cf* ensure_work2(pbh_plan* p) {
+    if (p->work2 || !p->work) return p->work2;
+    const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
+    const size_t len = bytes & ~(size_t)16383;
+    constexpr int NC = 6;
+    void* cand[NC] = {};
+    float t[NC];
+    int n = 0;
+    const bool probe = class_probing() && len >= ((size_t)512 << 20);   // (smaller copies live in the Infinity Cache)
+    while (n < (probe ? NC : 1)) {
+        if (dev_alloc(p, &cand[n], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
+        t[n++] = -1.f;
+    }
+    if (n == 0) return nullptr;
+    int pick = 0;
+    bool opposite = false;
+    float tmax = -1.f;
+    if (probe && n > 1) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            const unsigned grid = (unsigned)(len / 16 / 1024);
+            for (int rep = 0; rep < 6; ++rep)
+                for (int i = 0; i < n; ++i) {
+                    (void)hipEventRecord(e0, p->stream);
+                    hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)p->work, (float4*)cand[i], (int64_t)grid * 1024);
+                    (void)hipEventRecord(e1, p->stream);
+                    float ms = 0.f;
+                    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && (t[i] < 0 || ms < t[i]))
+                        t[i] = ms;
+                }
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipGetLastError();
+        for (int i = 0; i < n; ++i) {
+            if (t[i] > 0 && (t[pick] < 0 || t[i] < t[pick])) pick = i;
+            if (t[i] > tmax) tmax = t[i];
+        }
+        opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
+    }
+    for (int i = 0; i < n; ++i)
+        if (i != pick) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; }
+    p->work2 = (cf*)cand[pick];
+    if (opposite) {
+        p->cls_t_same = tmax;
+        p->cls_t_diff = t[pick];
+        p->cls_len = std::min<size_t>(len, (size_t)1 << 30);
+    }
+    static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;
+    if (trace) {
+        fprintf(stderr, "[pbhip] work2: candidate %d of %d; copies work -> candidate:", pick + 1, n);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.4f", t[i]);
+        fprintf(stderr, " ms%s\n", opposite ? "" : " (no two groups)");
+    }
+    return p->work2;
+}
+// class of a caller's buffer relative to the plan's work buffer: 0 = the same, 1 = the other, -1 = unknown (small buffers,
+// plans without an opposite-class pair, undecided probes).  The probe copies from `ptr` into work and into work2 (scratch
+// between calls), alternating; whichever is faster is the buffer of the other class.  Cached per (pointer, size).
+static int buffer_class(pbh_plan* p, const void* ptr, size_t bytes) {
+    if (!class_probing() || !ptr || !p->work || !p->work2 || p->cls_t_diff <= 0 || bytes < p->cls_len) return -1;
+    for (auto& e : p->cls_cache)
+        if (e.ptr == ptr && e.bytes == bytes) return e.cls;
+    float t1 = 0.f, t2 = 0.f;
+    int cls = -1;
+    if (probe_copy_pair(ptr, p->work, p->work2, p->cls_len, p->stream, &t1, &t2)) {
+        if (t1 < (1.f - kClassGap) * t2) cls = 1;        // faster into work: of the class work is NOT
+        else if (t2 < (1.f - kClassGap) * t1) cls = 0;
+    }
+    auto& e = p->cls_cache[p->cls_next++ & 7];
+    e.ptr = ptr;
+    e.bytes = bytes;
+    e.cls = cls;
+    static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;
+    if (trace) fprintf(stderr, "[pbhip] class of %p (%zu bytes): copy to work %.4f ms, to work2 %.4f ms -> %d\n", ptr, bytes, t1, t2, cls);
+    return cls;
+}
+#else
 static cf* ensure_work2(pbh_plan* p) {
     if (!p->work2 && p->work) {
         void* q = nullptr;
@@ -849,6 +1047,7 @@ static cf* ensure_work2(pbh_plan* p) {
     }
     return p->work2;
 }
+#endif
 
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
 static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode);
@@ -997,6 +1196,57 @@ static bool single_planar_ok(const pbh_plan* p) {
     // one-kernel form's 2-GiB addressing limit
     return mode == 2 || (int64_t)p->S * M >= (1LL << 21);
 }
+
+static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail, IoLayout io);
+static int run_steps(std::vector<Step>& steps, hipStream_t st);
+#ifndef PBH_F64
+// Which work buffer takes the Q4 intermediate of the four-pass schedule?  The allocation classes say it for clear cases, but a
+// 1-GiB probe copy separates the classes by 3-5 % only and the caller's buffers can be of either; the passes themselves are the
+// better instrument: on the first call with an (input, output) pair both assignments run twice, timed with events on the
+// plan's stream, and the faster one is kept for that pair (both produce the same output -- the runs are real runs).
+static int fd4_roles(pbh_plan* p, const cf* in, cf* out, const DetectTail& tail, const IoLayout& io) {
+    if (p->fd4_force >= 0) return p->fd4_force;
+    const void* okey = tail.out ? (const void*)tail.out : (const void*)out;
+    for (auto& e : p->role_cache)
+        if (e.in == in && e.out == okey && e.in) return e.swap;
+    // bit 0: the Q4 intermediate lives in work2 (else in work); bit 1: the inverse column pass runs out of place, back into
+    // the buffer the Q4 intermediate left (else in place on the planar one)
+    int swap = 0;
+    const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
+    if (class_probing() && bytes >= ((size_t)1 << 30) && p->stop > p->start) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        float best[4] = {-1.f, -1.f, -1.f, -1.f};
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            for (int rep = 0; rep < 2; ++rep)
+                for (int w = 0; w < 4; ++w) {
+                    p->fd4_force = w;
+                    auto steps = build_steps(p, in, out, tail, io);
+                    (void)hipEventRecord(e0, p->stream);
+                    const int rc = run_steps(steps, p->stream);
+                    (void)hipEventRecord(e1, p->stream);
+                    float ms = 0.f;
+                    if (rc == PBH_OK && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+                        (best[w] < 0 || ms < best[w]))
+                        best[w] = ms;
+                }
+            p->fd4_force = -1;
+            for (int w = 1; w < 4; ++w)
+                if (best[w] > 0 && best[swap] > 0 && best[w] < best[swap]) swap = w;
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipGetLastError();
+        static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;
+        if (trace) fprintf(stderr, "[pbhip] four-pass roles for (%p, %p): %.4f / %.4f ms (Q4 in work / work2, inverse in place), %.4f / %.4f (inverse out of place) -> %d\n",
+                           (const void*)in, okey, best[0], best[1], best[2], best[3], swap);
+    }
+    auto& e = p->role_cache[p->role_next++ & 7];
+    e.in = in;
+    e.out = okey;
+    e.swap = swap;
+    return swap;
+}
+#endif
 
 static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
                                      IoLayout io = IoLayout()) {
@@ -1238,7 +1488,16 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         const int chirp_split = unsplit ? p->P : 1;
         const bool fuse_radix = P > 1 && !in_sm && !out_sm && radix_layout_ok(S, P, N, N2);
         const int64_t nvalid = io.in_valid >= 0 ? io.in_valid : N;
-        if (fuse_radix) {
+        // Four-pass schedule (fd4_kernels.hpp): pass 1 reads the caller's block itself and leaves Q4 order in `work`, the row
+        // pass writes planar rows into the second work buffer, where the inverse column pass then works in place.
+        cf* fdB = nullptr;
+#ifndef PBH_F64
+        if (fd4_ok(p) && !in_sm && !out_sm && !unsplit && !fuse_radix && !io.mix_ft && io.in_valid < 0 && !depth_mode() && !oop_mode() &&
+            colp_mode() != 0)
+            fdB = ensure_work2(p);
+#endif
+        if (fdB) {
+        } else if (fuse_radix) {
             const int Pf = P;
             steps.push_back({"k_deinterleave", [=](hipStream_t st) {
                 return launch_deint_radix(S, Pf, in, work, N, N2, N1, nvalid, st);
@@ -1317,6 +1576,29 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             }
         } else {
 #endif
+#ifndef PBH_F64
+        if (fdB) {
+            // roles of the two work buffers (of opposite allocation class where that could be arranged, ensure_work2): the
+            // Q4 intermediate X should be the one whose class differs from the caller's input's, so that every pass streams
+            // between allocations of different class, in -> X -> Y -> X -> out; fd4_roles finds out which one that is
+            cf *X = work, *Y = fdB;
+            const int roles = fd4_roles(p, in, out, tail, io);
+            if (roles & 1) std::swap(X, Y);
+            const ColfdParams fp{in, X, S, N2, tw, p->tw16k};
+            steps.push_back({"k_col_fwd", [=](hipStream_t st) { return launch_colfd(Q, fp, st); }});
+            const RowqParams rq{X, Y, p->chirp_phase, p->tw16k, S, N1, p->npol, (real)(1.0 / (double)p->N)};
+            steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_rowq(rq, st); }});
+            if (roles & 2) {           // inverse column pass out of place, Y -> X
+                cp3.ld = Y;
+                cp3.ld_plane = N;
+                cp3.data = X;
+                fdB = X;               // ... where the time-ordered series then are
+            } else {
+                cp3.data = Y;
+                fdB = Y;
+            }
+        } else {
+#endif
         steps.push_back({"k_col_fwd", [=](hipStream_t st) {
             return colp ? launch_colq<OP_FWD_TW>(Q, cp1, st) : launch_col<OP_FWD_TW>(N1, c1, st);
         }});
@@ -1341,6 +1623,9 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
         } else
 #endif
         steps.push_back({"k_row_fused", [=](hipStream_t st) { return launch_row(N2, rp, st); }});
+#ifndef PBH_F64
+        }
+#endif
         if (workB) {
             cp3.ld = work;
             cp3.ld_plane = N;
@@ -1393,7 +1678,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
 #ifndef PBH_F64
         }
 #endif
-        const cf* wlast = workB ? workB : work;   // where the last column pass left the time-ordered series
+        const cf* wlast = fdB ? fdB : (workB ? workB : work);   // where the last column pass left the time-ordered series
         const bool fuse_out = fuse_radix && !tail.out;   // the detect tail reads time-ordered planar data
         if (P > 1 && !fuse_out) {
             if (out_sm && !tail.out) {   // the inverse stage writes the caller's series-major output, cropped
@@ -2197,6 +2482,20 @@ int pbh_plan_set_variant(pbh_plan* p, int variant) {
             return fail(PBH_ERR_UNSUPPORTED, "block3 needs nchan*npol % 4 == 0 and nsample <= 2^24");
     }
     p->variant = variant;
+    return PBH_OK;
+}
+
+int pbh_plan_buffer_class(pbh_plan* p, const void* dev_ptr, int64_t bytes, int* cls) {
+    if (!p || !cls) return fail(PBH_ERR_INVALID, "NULL argument");
+    *cls = -1;
+#ifndef PBH_F64
+    HIPCHECK(hipSetDevice(p->device));
+    if (fd4_ok(p) && !p->work2) (void)ensure_work2(p);
+    if (dev_ptr && bytes > 0) *cls = buffer_class(p, dev_ptr, (size_t)bytes);
+#else
+    (void)dev_ptr;
+    (void)bytes;
+#endif
     return PBH_OK;
 }
 
@@ -4060,26 +4359,32 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
 }
 
 #ifndef PBH_F64
-int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
-    if (!ms_mean || bytes < 16 || iters <= 0) return fail(PBH_ERR_INVALID, "bad argument");
+// mode 0: copy a -> b (two buffers of `bytes`); mode 1: read-modify-write of ONE buffer in place (what the three middle
+// passes do to the planar work buffer).  Mean milliseconds per launch over `iters` launches, HIP events on the null stream.
+int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_mean) {
+    if (!ms_mean || bytes < 16 || iters <= 0 || mode < 0 || mode > 1) return fail(PBH_ERR_INVALID, "bad argument");
     HIPCHECK(hipSetDevice(device));
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = dev_alloc(nullptr, &a, (size_t)bytes);
-    if (rc == PBH_OK) rc = dev_alloc(nullptr, &b, (size_t)bytes);
+    if (rc == PBH_OK && mode == 0) rc = dev_alloc(nullptr, &b, (size_t)bytes);
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return x == hipSuccess; };
     float ms = 0.f;
     if (rc == PBH_OK) {
         const int64_t n = bytes / 16;
         const unsigned grid = (unsigned)((n + 1023) / 1024);
-        ok(hipMemset(a, 1, (size_t)bytes));
+        auto launch = [&] {
+            if (mode == 0) hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+            else hipLaunchKernelGGL(k_copy<true>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)a, n);
+        };
+        ok(hipMemset(a, 0, (size_t)bytes));
         ok(hipEventCreate(&e0));
         ok(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+        launch();
+        launch();
         ok(hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
+        for (int i = 0; i < iters; ++i) launch();
         ok(hipGetLastError());
         ok(hipEventRecord(e1, 0));
         ok(hipEventSynchronize(e1));
@@ -4090,10 +4395,11 @@ int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) {
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (rc != PBH_OK) return rc;
-    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("copy bench: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("stream bench: ") + hipGetErrorString(e));
     *ms_mean = ms / iters;
     return PBH_OK;
 }
+int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) { return pbh_stream_bench(device, bytes, iters, 0, ms_mean); }
 
 #endif  // !PBH_F64
 

@@ -21,6 +21,7 @@
     int P##plan_set_stream(P##plan*, void*);                                                                    \
     int P##plan_set_variant(P##plan*, int);                                                                     \
     int P##plan_info(const P##plan*, pbh_plan_info_t*);                                                         \
+    int P##plan_buffer_class(P##plan*, const void*, int64_t, int*);                                             \
     int P##chirp_generate(P##plan*, double, double, const double*, double);                                     \
     int P##chirp_upload(P##plan*, const void*, int);                                                            \
     int P##chirp_upload_as(P##plan*, const void*, int, int);                                                    \
@@ -62,6 +63,7 @@ int pbh32_device_count(void);
 const char* pbh32_version(void);
 int pbh32_chirp_function(int, void*, double, int64_t, double, double, double, void*, int);
 int pbh32_copy_bench(int, int64_t, int, float*);
+int pbh32_stream_bench(int, int64_t, int, int, float*);
 int pbh32_real_to_complex(int, void*, const void*, void*, int64_t, int);
 int pbh32_incoherent(int, void*, const void*, void*, int64_t, int, int, const int64_t*);
 int pbh32_incoherent_series(int, void*, const void*, int64_t, void*, int64_t, int64_t, int, int, int, const int64_t*);
@@ -129,6 +131,7 @@ int pbh_plan_destroy(pbh_plan* p) {
 int pbh_plan_set_stream(pbh_plan* p, void* s) { FORWARD(p, pbh32_plan_set_stream(P32(p), s), pbh64_plan_set_stream(P64(p), s)); }
 int pbh_plan_set_variant(pbh_plan* p, int v) { FORWARD(p, pbh32_plan_set_variant(P32(p), v), pbh64_plan_set_variant(P64(p), v)); }
 int pbh_plan_info(const pbh_plan* p, pbh_plan_info_t* i) { FORWARD(p, pbh32_plan_info(P32(p), i), pbh64_plan_info(P64(p), i)); }
+int pbh_plan_buffer_class(pbh_plan* p, const void* d, int64_t b, int* c) { FORWARD(p, pbh32_plan_buffer_class(P32(p), d, b, c), pbh64_plan_buffer_class(P64(p), d, b, c)); }
 int pbh_chirp_generate(pbh_plan* p, double c, double dt, const double* f, double r) {
     FORWARD(p, pbh32_chirp_generate(P32(p), c, dt, f, r), pbh64_chirp_generate(P64(p), c, dt, f, r));
 }
@@ -259,6 +262,7 @@ int pbh_real_to_complex(int device, void* stream, const void* in, void* out, int
     return done(PBH_C64, pbh32_real_to_complex(device, stream, in, out, nreal, nseries));
 }
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms) { return done(PBH_C64, pbh32_copy_bench(device, bytes, iters, ms)); }
+int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms) { return done(PBH_C64, pbh32_stream_bench(device, bytes, iters, mode, ms)); }
 
 // ---- node-level sharing of device buffers between the ranks of one node (one process per GPU) -----------------
 // The reference gathers chunked results with Signal.compute() (pulsarbat/core.py:298-309).  Here the gather is done by

@@ -25,6 +25,22 @@ def series_errors(got, ref):
     return (num / den).max(), (np.abs(got - ref).max(axis=0) / rms).max()
 
 
+def same_kernels_or_close(a, b, rel=5e-7):
+    """Two routes through the library that run the same butterflies.  Where they also run the same KERNELS the results are
+    bit-identical; since round 4 the sample-major route of quad-series blocks is the four-pass schedule
+    (csrc/fd4_kernels.hpp), whose row kernel hipcc contracts into multiply-adds differently: equal to the last bits then,
+    not always bit for bit (tests/test_gpu_fd4.py holds both schedules against each other and against the oracle)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if np.array_equal(a, b):
+        return True
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    num = np.linalg.norm((a2 - b2).astype(np.complex128 if np.iscomplexobj(a2) else np.float64), axis=0)
+    den = np.linalg.norm(b2.astype(np.complex128 if np.iscomplexobj(b2) else np.float64), axis=0)
+    return bool((num <= rel * den).all())
+
+
 def make_signal(x, sr, fc, **kw):
     if x.ndim == 3 and x.shape[2] == 2:
         return pb.DualPolarizationSignal(x, sample_rate=sr * u.Hz, center_freq=fc * u.Hz,
@@ -334,7 +350,8 @@ def test_full_size_properties():
     # the series-major (time-fastest) device layout gives the same bits with two kernels fewer
     zs = pb.DualPolarizationSignal(pb.DeviceArray(x1).to_series_major(), **kw)
     ys = pb.coherent_dedispersion(zs, pb.DM(dm))
-    assert ys.data.series_major_pitch() is not None and torch.equal(ys.data.tensor, y1.data.tensor)
+    assert ys.data.series_major_pitch() is not None
+    assert same_kernels_or_close(ys.data.tensor.cpu().numpy(), y1.data.tensor.cpu().numpy())
     del zs, ys
     # one series against the oracle (1-D, 2^24: a few seconds of CPU)
     c, p = 5, 1
@@ -616,7 +633,13 @@ def test_series_major_io(shape, dm, dtype):
     # uses the persistent column kernel too (column transforms of 64 points and more)
     y0 = plan.dedisperse(zd.data)
     if plan.info["n1"] >= 64:
-        assert np.array_equal(np.asarray(y0), np.asarray(y3))
+        assert same_kernels_or_close(y0, y3)
+        import os
+        os.environ["PBH_FD4"] = "0"      # the five-pass schedule: the same kernels as the series-major route, bit for bit
+        try:
+            assert np.array_equal(np.asarray(plan.dedisperse(zd.data)), np.asarray(y3))
+        finally:
+            os.environ.pop("PBH_FD4", None)
     else:
         assert series_errors(y0, np.asarray(y3))[0] < (2e-6 if dtype == np.complex64 else 1e-13)
 
@@ -696,7 +719,7 @@ def test_detect_inside_the_column_pass(mode, nscrunch, dm, ref):
     assert rel.max() < 2e-5, f"start {start}: max relative difference {rel.max():.2e}"
     zs = type(z).like(z, z.data.to_series_major())
     got_s, start_s = pb.dedisperse_detect(zs, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=nscrunch)
-    assert start_s == start and np.array_equal(np.asarray(got_s), got)
+    assert start_s == start and same_kernels_or_close(got_s, got, rel=2e-6)
     if mode == "I" and nscrunch == 1024 and ref is None:
         # a chirp given by the caller (complex64 rows, k_row instead of the phase-row kernel in front of the detecting pass)
         c = pb.DM(dm).chirp_from_signal(z)   # device-resident, (n, nchan, 1)
@@ -758,7 +781,7 @@ def test_detect_inside_the_column_pass_wider_tiles(log2n, mode, nscrunch, dm):
     zs = z.to_device()
     zs = type(zs).like(zs, zs.data.to_series_major())
     got_s, _ = pb.dedisperse_detect(zs, pb.DM(dm), mode=mode, nscrunch=nscrunch)
-    assert np.array_equal(np.asarray(got_s), got)
+    assert same_kernels_or_close(got_s, got, rel=2e-6)
 
 
 @pytest.mark.gpu
