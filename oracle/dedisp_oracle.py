@@ -190,6 +190,27 @@ def scrunch(a, nscrunch):
     return a[: n * nscrunch].reshape((n, nscrunch) + a.shape[1:]).sum(axis=1)
 
 
+def detect_f64(z, mode, nscrunch=1, pol_type="linear"):
+    """Detection (+ time scrunch) of dedispersed voltages with the POWER SUMS IN FLOAT64 -- the yardstick the detect tail's
+    parity tests use ("Stokes/scrunch outputs <= 1e-5 relative").  The reference computes to_intensity /
+    to_stokes in the data's own precision (core.py:766-774, 930-966) and has no scrunch; summing 1024 float32 powers one
+    after the other is itself ~1e-5 noisy, so a float32 oracle cannot tell a 1e-5 error of the device path from its own.
+    ``mode``: "intensity" (every series, |z|^2), "I" (Stokes I per channel) or "stokes" (I, Q, U, V on a new last axis).
+    Returns (values float64, scale float64): ``scale`` is the Stokes-I (or |z|^2) sum the absolute errors are measured
+    against -- Q, U and V change sign, only I is an all-positive sum."""
+    z = np.asarray(z).astype(np.complex128)
+    if mode == "intensity":
+        v = to_intensity(z)
+        sc = v
+    else:
+        st = to_stokes(z, pol_type)
+        v = st[:, :, 0] if mode == "I" else st
+        sc = st[:, :, 0] if mode == "I" else st[:, :, :1]
+    if nscrunch > 1:
+        v, sc = scrunch(v, nscrunch), scrunch(sc, nscrunch)
+    return v, np.broadcast_to(sc, v.shape)
+
+
 def synthetic_block(shape, seed):
     """SURVEY.md 8(d) synthetic input: complex standard normal / sqrt(2), complex64."""
     rng = np.random.default_rng(seed)

@@ -5,6 +5,7 @@ The shared object is kept next to its sources (``pulsarbat_amd/csrc/libpbhip.so`
 repository snapshot carries it to the GPU box.
 """
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -12,9 +13,10 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpbhip.so")
 SOURCES = ["pbhip.hip", "pbhip_api.cpp"]
-HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", "mixed_kernels.hpp",
+HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", "mixed_kernels.hpp", "fd4_kernels.hpp", "host_sched.hpp",
            os.path.join("..", "..", "include", "pbhip.h")]
 ARCH = "gfx950"
+STAMP = LIB + ".sources"   # SHA-256 of the sources and flags the library was built from (travels with it to the GPU box)
 
 
 def _hipcc():
@@ -24,11 +26,24 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+def source_hash():
+    """SHA-256 over the sources, headers and build flags: what decides whether the library on disk is the one these
+    sources make (mtimes do not survive a repository snapshot; round 3's build() compared mtimes and could leave a box
+    running whatever .so the snapshot carried)."""
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(("flags:" + os.environ.get("PBH_EXTRA_FLAGS", "") + ":" + ARCH).encode())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -59,6 +74,8 @@ def build(force=False, verbose=False):
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stderr[-4000:])
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     if verbose:
         print("built", LIB)
     return LIB

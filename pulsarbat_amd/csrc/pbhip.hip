@@ -65,8 +65,26 @@
 #include "kernels.hpp"
 #include "mixed_kernels.hpp"
 #include "fd4_kernels.hpp"
+#include "host_sched.hpp"
 
 using namespace PBH_NS;
+
+// ---- environment switches ---------------------------------------------------------------------------------
+// SHIPPED (read by every build, documented in README.md "Environment"): PBH_FD4 (0: five-pass schedule only), PBH_CLASS
+// (0: no allocation-class probing), PBH_TRACE_ALLOC (allocations and placement decisions on stderr), PBH_STREAM_WINDOW_MB and
+// PBH_STREAM_EPOCH (device window of the streaming drivers), PBH_QMAX (rows of a column tile: forces the split column transform
+// at small sizes), PBH_ROW_GRID (workgroups of the persistent kernels; default one per CU), PBH_MIXED (7-smooth lengths: 0
+// padded convolution, 1 one-level plans, 2 two-level too).  Everything else is an EXPERIMENT switch of the A/B runs recorded
+// in DESIGN.md 6-6d and exists only in builds made with PBH_EXTRA_FLAGS="-DPBH_DIAGNOSTIC": a product build takes the default
+// (tests/test_abi.py counts the getenv calls of the shipped sources).
+static inline const char* diag_env(const char* name) {
+#ifdef PBH_DIAGNOSTIC
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---- error plumbing ------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -102,7 +120,7 @@ static int64_t next_pow2_at_least(int64_t x) {
 // column transform (k_radix_p / k_deint_radix), 2^k = Q * 2^tile with PBH_R <= Q <= one-line-wide tiles.
 // PBH_ODD=0 turns this off (such lengths then go through the convolution plan like any other).
 static int native_odd_factor(int64_t n) {
-    static const bool on = [] { const char* e = getenv("PBH_ODD"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_ODD"); return e ? atoi(e) != 0 : true; }();
     if (!on) return 0;
     const int64_t qmax = (int64_t)kTilePoints * (int64_t)sizeof(cf) / 128;
     for (int m : {3, 5, 7}) {
@@ -134,7 +152,7 @@ static bool is_7smooth(int64_t n) {
 }
 static bool split_levels(int64_t n1, int64_t* qout) {
     int64_t q = 0;
-    static const int64_t forced = [] { const char* e = getenv("PBH_MIX_Q"); return e ? atoll(e) : 0LL; }();   // (timing runs)
+    static const int64_t forced = [] { const char* e = diag_env("PBH_MIX_Q"); return e ? atoll(e) : 0LL; }();   // (timing runs)
     if (n1 <= kMixMaxLen) q = n1;
     else if (forced > 1 && n1 % forced == 0 && forced <= kMixMaxLen && n1 / forced <= kMixMaxLen) q = forced;
     else {
@@ -175,14 +193,14 @@ static bool mixed_geometry(int64_t n, int* N1, int* N2, int* P) {
 // levels of at most 1024 rows.  The column passes take pieces of up to 512 elements of a row, the last one of a row short
 // (rows start at multiples of 2^k elements: 16 to 128 bytes).  PBH_ROWMIX=0: off.
 static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
-    static const bool on = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_ROWMIX"); return e ? atoi(e) != 0 : true; }();
     static const int mode = [] { const char* e = getenv("PBH_MIXED"); return e ? atoi(e) : 2; }();
     if (!on || mode < 2 || n < 4096 || is_pow2(n) || !is_7smooth(n)) return false;
     int k = 0;
     while (((n >> k) & 1) == 0) ++k;
     // (odd lengths too: their planar rows start at odd element offsets, which costs the layout kernels unaligned 16-byte
     //  accesses and nothing else; PBH_ROWMIX_KMIN=1 leaves them to the convolution plan)
-    static const int kmin = [] { const char* e = getenv("PBH_ROWMIX_KMIN"); return e ? atoi(e) : 0; }();
+    static const int kmin = [] { const char* e = diag_env("PBH_ROWMIX_KMIN"); return e ? atoi(e) : 0; }();
     if (k < kmin) return false;
     if (k > 4) k = 4;
     // the longest row that leaves a splittable N1 (measured on 10 935 000 x 16: rows of 1000 points 5.03 ms, 600: 5.06,
@@ -206,7 +224,7 @@ static bool rowmix_geometry(int64_t n, int* N1, int* N2, int* P) {
 // plans there are) within 2.2 N (8 268 750: 3.30 against 3.89 ms; 7 873 200: 3.29 / 3.35), and loses with L = m * 2^k
 // (12 301 875: 5.82 / 5.70; 7 144 200: 3.65 / 3.09).  profiles/r02_7smooth.txt.  PBH_ROWMIX=2: always the mixed-radix rows.
 static bool rowmix_pays(int64_t n) {
-    static const int mode = [] { const char* e = getenv("PBH_ROWMIX"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char* e = diag_env("PBH_ROWMIX"); return e ? atoi(e) : 1; }();
     if (mode >= 2) return true;
     const int64_t L = convolution_length(2 * n - 1);
     return !is_pow2(L) || (double)L / (double)n >= 2.2;
@@ -325,7 +343,7 @@ static int resolved_variant(const pbh_plan* p) {
 // ---- kernel dispatch by FFT length ---------------------------------------------------------------------------
 static int block_lane_order() {
     static int r = [] {
-        const char* e = getenv("PBH_BLOCK_LANE_ORDER");
+        const char* e = diag_env("PBH_BLOCK_LANE_ORDER");
         return e ? atoi(e) : 0;
     }();
     return r;
@@ -401,7 +419,7 @@ static int launch_col(int M, const ColParams& prm0, hipStream_t st) {
 // persistent planar in-place column pass (planar5).  PBH_COLP: 0 = one-tile workgroups (k_col),
 // 1 = k_colq with a static tile stride, 2 (default) = k_colq with tiles handed out by an atomic counter
 static int colp_mode() {
-    static int m = [] { const char* e = getenv("PBH_COLP"); return e ? atoi(e) : 2; }();
+    static int m = [] { const char* e = diag_env("PBH_COLP"); return e ? atoi(e) : 2; }();
     return m;
 }
 #ifndef PBH_F64
@@ -458,7 +476,7 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     if (FR > 1 && prm.N1 > 1) tiles = (prm.nrows / prm.N1) * ((prm.N1 + FR - 1) / FR);   // tiles do not straddle series (k_row)
     if (tiles > row_grid()) tiles = row_grid();
 #if defined(PBH_DIAGNOSTIC) && !defined(PBH_F64)  // ablation builds: -DPBH_DIAGNOSTIC, then PBH_ROW_ABL=1|2|3
-    static int abl = [] { const char* e = getenv("PBH_ROW_ABL"); return e ? atoi(e) : 0; }();
+    static int abl = [] { const char* e = diag_env("PBH_ROW_ABL"); return e ? atoi(e) : 0; }();
     if (M == 16384 && abl == 1) return launch_tile_kernel(k_row<16384, 32, true, 1>, prm, tiles, 512, st);
     if (M == 16384 && abl == 2) return launch_tile_kernel(k_row<16384, 32, true, 2>, prm, tiles, 512, st);
     if (M == 16384 && abl == 3) return launch_tile_kernel(k_row<16384, 32, true, 3>, prm, tiles, 512, st);
@@ -472,7 +490,7 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
         const int rc = abl == 4 ? launch_tile_kernel(k_row<16384, 32, true, 4>, q, tiles, 512, st)
                                 : launch_tile_kernel(k_row<16384, 32, true, 5>, q, tiles, 512, st);
         if (rc != PBH_OK) return rc;
-        if (const char* path = getenv("PBH_ROW_DBG")) {
+        if (const char* path = diag_env("PBH_ROW_DBG")) {
             HIPCHECK(hipStreamSynchronize(st));
             std::vector<unsigned long long> h((size_t)dbg_n);
             HIPCHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -488,7 +506,7 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
     // counter.  PBH_ROW_SPREAD=2 keeps the ticks but walks tiles with a static stride; the older forms
     // (0 = three bursts, 1 = per stage) exist in -DPBH_DIAGNOSTIC builds only, for the A/B numbers of
     // DESIGN.md 6 (config 2: 1.16 / 1.14 / 1.11 / 1.085 ms).
-    static const int spread = [] { const char* e = getenv("PBH_ROW_SPREAD"); return e ? atoi(e) : 3; }();
+    static const int spread = [] { const char* e = diag_env("PBH_ROW_SPREAD"); return e ? atoi(e) : 3; }();
 #ifdef PBH_DIAGNOSTIC
     if (spread == 1) {
         switch (M) {
@@ -517,13 +535,13 @@ static int launch_row(int M, const RowParams& prm, hipStream_t st) {
 }
 
 static int depth_mode() {
-    static const int m = [] { const char* e = getenv("PBH_DEPTH"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = diag_env("PBH_DEPTH"); return e ? atoi(e) : 0; }();
     return m;
 }
 #ifndef PBH_F64
 // PBH_ROW_PHASE=0 keeps the complex64-chirp row kernel for generated chirps too (A/B runs)
 static bool row_phase_enabled() {
-    static const bool on = [] { const char* e = getenv("PBH_ROW_PHASE"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_ROW_PHASE"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
 // rows of M = N2 points, 2^tile / M of them (consecutive k1 of one series) per tile
@@ -535,15 +553,15 @@ static bool rowp_ok(int N1, int N2) {
 // 2^14-point rows go through k_rowp16, which reads its phase rows in its own order; PBH_ROW16=0 keeps the 8-byte-per-lane
 // kernel (A/B runs).  Decided when the chirp is written (the plan remembers: pbh_plan::phase16).
 static bool rowp16_on(int N2) {
-    static const bool row16 = [] { const char* e = getenv("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
+    static const bool row16 = [] { const char* e = diag_env("PBH_ROW16"); return e ? atoi(e) != 0 : true; }();
     return row16 && N2 == kTilePoints;
 }
 static int launch_rowp(int M, RowpParams prm, hipStream_t st) {
     const int FR = kTilePoints / M;
     int64_t tiles = (int64_t)prm.nchan * ((prm.N1 + FR - 1) / FR);
     if (tiles > row_grid()) tiles = row_grid();
-    static const bool nofft = [] { const char* e = getenv("PBH_ROW16_NOFFT"); return e ? atoi(e) != 0 : false; }();
-    static const bool defer = [] { const char* e = getenv("PBH_ROW16_DEFER"); return e ? atoi(e) != 0 : false; }();   // deferred stores (A/B)
+    static const bool nofft = [] { const char* e = diag_env("PBH_ROW16_NOFFT"); return e ? atoi(e) != 0 : false; }();
+    static const bool defer = [] { const char* e = diag_env("PBH_ROW16_DEFER"); return e ? atoi(e) != 0 : false; }();   // deferred stores (A/B)
     if (prm.phase16 && M == kTilePoints) {
         if (nofft) return launch_tile_kernel(k_rowp16<PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         if (prm.chan_freq && prm.cP == 1)
@@ -570,7 +588,7 @@ static int fd4_mode() {   // (read at every call: the tests switch it inside one
 }
 // PBH_FD4_SP=<c><r>: pacing variant of the column (tens) and row (units) kernels (A/B runs)
 static int fd4_sp() {
-    const char* e = getenv("PBH_FD4_SP");
+    const char* e = diag_env("PBH_FD4_SP");
     return e ? atoi(e) : 0;
 }
 // grid of a gang-scheduled kernel: a multiple of 8 * members (blocks b, b + 8, ... share an XCD), one workgroup per CU
@@ -642,7 +660,7 @@ static int blk_series(int S, int64_t N) {
 #ifndef PBH_F64
     if ((S & (S - 1)) == 0 && S <= 128) return 0;   // k_*_p2 row transposes
 #endif
-    static const bool on = [] { const char* e = getenv("PBH_BLK_LAYOUT"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_BLK_LAYOUT"); return e ? atoi(e) != 0 : true; }();
     if (!on && S <= 128) return 0;
     int sb = 4;
     while (sb < S && sb < 64) sb <<= 1;
@@ -761,7 +779,7 @@ static bool reint_detect_ok(int S, int npol, int mode, int64_t N) {
     (void)S; (void)npol; (void)mode; (void)N;
     return false;
 #else
-    static const bool on = [] { const char* e = getenv("PBH_DETECT_REINT"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_DETECT_REINT"); return e ? atoi(e) != 0 : true; }();
     // power-of-two counts up to 128: k_reinterleave_p2; many series and other even counts: k_reint_blk
     if (!on || !(((S & (S - 1)) == 0 && S >= 2 && S <= 128) || blk_series(S, N) != 0)) return false;
     return mode == PBH_DETECT_INTENSITY || npol == 2;
@@ -822,7 +840,7 @@ static int launch_reint_detect(const cf* work, real* out, int64_t start, int64_t
 
 // Layout passes with the radix-P stage folded in (float32, 2 <= S <= 128 a power of two, tiles of >= 16 samples).
 static bool radix_layout_ok(int S, int P, int64_t N, int N2) {
-    static const bool on = [] { const char* e = getenv("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_RADIX_FUSE"); return e ? atoi(e) != 0 : true; }();
     if (!on || S < 2 || S > 128 || (S & (S - 1)) != 0) return false;
     if (P != 2 && P != 3 && P != 4 && P != 5 && P != 7 && P != 8 && P != 16) return false;
     const int E = radix_tile_e(P) * 8 / (int)sizeof(cf), TN = E / S;   // RadixTile<P>
@@ -909,7 +927,7 @@ struct DetectTail {
 // product's pitch (column passes 0.846 -> 0.856 / 0.754 -> 0.759 ms, row pass 1.00 -> 0.99) and 1.3 % of the step with a
 // padded pitch on top (profiles/r03_colq_pitch_oop.txt) -- for a second workspace of S * N elements.
 static int oop_mode() {
-    static const int m = [] { const char* e = getenv("PBH_OOP"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = diag_env("PBH_OOP"); return e ? atoi(e) : 0; }();
     return m;
 }
 #ifndef PBH_F64
@@ -1055,7 +1073,7 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode);
 // Detection inside the inverse column pass (k_colq<.., DET> + k_detect_reduce): for |z|^2 and Stokes I, whose sums need one
 // series at a time.  PBH_DETECT_COLQ=0 restores the separate read pass over the dedispersed voltages (k_detect_planar).
 static bool detect_in_colq() {
-    static const bool on = [] { const char* e = getenv("PBH_DETECT_COLQ"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_DETECT_COLQ"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
 static real* ensure_det_part(pbh_plan* p, size_t bytes) {
@@ -1082,7 +1100,7 @@ static int mix_wlog2(int L, int N2) {
 }
 template <int DIR>
 static int launch_colmix(const MixParams& prm, hipStream_t st) {
-    static const bool nostage = [] { const char* e = getenv("PBH_MIX_NOSTAGE"); return e ? atoi(e) != 0 : false; }();   // (timing runs)
+    static const bool nostage = [] { const char* e = diag_env("PBH_MIX_NOSTAGE"); return e ? atoi(e) != 0 : false; }();   // (timing runs)
     MixParams q = prm;
     if (nostage) q.nstage = 0;
     const size_t lds = ((size_t)prm.L << prm.wlog2) * sizeof(cf) + (size_t)prm.L * sizeof(cf) + (size_t)prm.L * sizeof(unsigned short) + 16 +
@@ -1114,7 +1132,7 @@ static int launch_rowmix(const pbh_plan* p, cf* work, hipStream_t st, bool fwd_o
 // threads (9 953 280 = 2^13 * 3 * 405, 16 series: 1.22 ms per pass as a tile, 0.75 for 5 rows; profiles/r03_mix_split.txt).
 // PBH_MIX_RADIXP=0: the tile kernel for every P.
 static bool mix_radix_p(int P) {
-    static const bool on = [] { const char* e = getenv("PBH_MIX_RADIXP"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_MIX_RADIXP"); return e ? atoi(e) != 0 : true; }();
     return on && (P == 2 || P == 3 || P == 4 || P == 5 || P == 7 || P == 8);
 }
 
@@ -1186,7 +1204,7 @@ static int launch_reinterleave_parts(const cf* work, cf* out, int64_t start, int
 // One-tile plans (nsample <= 2^tile) whose blocks have many series run as layout pass + planar row pass + layout pass
 // instead of the single interleaved kernel (build_steps); needs the planar work buffer (allocated at plan creation).
 static bool single_planar_ok(const pbh_plan* p) {
-    static const int mode = [] { const char* e = getenv("PBH_SINGLE_PLANAR"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char* e = diag_env("PBH_SINGLE_PLANAR"); return e ? atoi(e) : 1; }();
     if (!mode || p->N1 != 1 || p->bsL || p->plain_fft || !is_pow2(p->N)) return false;
     const int64_t M = p->N;
     if (M < 1024 || M > kTilePoints) return false;                  // the planar row kernels' lengths (FOR_ROW_M)
@@ -1607,7 +1625,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
             RowpParams rpp{work, p->chirp_phase, p->tw16k, p->nchan, N1, p->npol, (real)(1.0 / (double)p->N), ctr + 2};
             rpp.cP = chirp_split;
             rpp.phase16 = p->phase16;
-            static const bool otf = [] { const char* e = getenv("PBH_ROW_OTF"); return e ? atoi(e) != 0 : false; }();
+            static const bool otf = [] { const char* e = diag_env("PBH_ROW_OTF"); return e ? atoi(e) != 0 : false; }();
             if (otf && p->phase16 && chirp_split == 1 && is_pow2(p->N)) {   // phase computed in the kernel (A/B switch)
                 rpp.chan_freq = p->chan_freq;
                 rpp.coeff = p->gen_coeff;
@@ -1889,71 +1907,14 @@ int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_
 }
 
 // Reader-side decode (include/pbhip.h): every byte the kernel will touch is bounds-checked here first.
-struct DecodeSpan {
-    int64_t b0, b1;     // first / last block touched
-    size_t off, len;    // byte range [off, off + len) of the raw buffer that is read
-};
+typedef pbh_host::Span DecodeSpan;   // {b0, b1: first / last block touched; off, len: bytes [off, off + len) of the raw buffer read}
 
+// (the arithmetic lives in host_sched.hpp, where the CPU box runs it under the sanitizers)
 static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan, int npol, size_t raw_bytes,
                        DecodeSpan* sp) {
-    if (!L) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (nsample <= 0 || first < 0 || nchan <= 0 || npol <= 0) return fail(PBH_ERR_INVALID, "bad dimensions");
-    if (L->ncomp != 1 && L->ncomp != 2) return fail(PBH_ERR_INVALID, "ncomp must be 1 or 2");
-    if (!((L->nbits == 8 && (L->code == 0 || L->code == 1)) || ((L->nbits == 2 || L->nbits == 4) && L->code == 0)))
-        return fail(PBH_ERR_UNSUPPORTED, "payload coding: 8 bits (code 0/1), 4 bits or 2 bits");
-    if (L->blk_samples <= 0 || L->blk_stride < 0 || L->hdr_bytes < 0) return fail(PBH_ERR_INVALID, "bad block geometry");
-    if ((int64_t)nchan * npol > 65535LL * 64) return fail(PBH_ERR_UNSUPPORTED, "too many series");
-    const int64_t b0 = first / L->blk_samples, b1 = (first + nsample - 1) / L->blk_samples;
-    // every product of caller-supplied strides, counts and sizes below is checked: a layout whose addressing does not fit
-    // 63 bits is rejected, not wrapped (the bounds checks that follow are only as good as the arithmetic under them)
-    bool ovf = false;
-    auto mul = [&](int64_t a, int64_t b) { int64_t r = 0; ovf |= __builtin_mul_overflow(a, b, &r); return r; };
-    auto add = [&](int64_t a, int64_t b) { int64_t r = 0; ovf |= __builtin_add_overflow(a, b, &r); return r; };
-    if (first > INT64_MAX - nsample) return fail(PBH_ERR_INVALID, "sample range overflows");
-    // [lo, hi]: element indices reached over time samples [ta, tb] of one payload
-    auto reach = [&](int64_t ta, int64_t tb, int64_t* lo, int64_t* hi) {
-        *lo = *hi = L->elem0;
-        auto span = [&](int64_t stride, int64_t a, int64_t b) {
-            *lo = add(*lo, stride >= 0 ? mul(stride, a) : mul(stride, b));
-            *hi = add(*hi, stride >= 0 ? mul(stride, b) : mul(stride, a));
-        };
-        span(L->stride_t, ta, tb);
-        span(L->stride_c, 0, nchan - 1);
-        span(L->stride_p, 0, npol - 1);
-    };
-    const int64_t bits = (int64_t)L->nbits * L->ncomp;
-    const int64_t t_first = first - b0 * L->blk_samples, t_last = first + nsample - 1 - b1 * L->blk_samples;
-    int64_t lo, hi, lo2, hi2;
-    reach(b1 > b0 ? 0 : t_first, t_last, &lo, &hi);   // the last block: what bounds the buffer
-    if (ovf || hi < 0 || hi > (INT64_MAX - 8) / bits - 1) return fail(PBH_ERR_INVALID, "payload addressing overflows");
-    const int64_t pay_hi = ((hi + 1) * bits + 7) / 8;
-    if (b1 > b0) {                                      // earlier blocks are read up to their last sample
-        reach(b1 > b0 + 1 ? 0 : t_first, L->blk_samples - 1, &lo2, &hi2);
-        if (b1 > b0 + 1) {
-            int64_t lo3, hi3;
-            reach(t_first, L->blk_samples - 1, &lo3, &hi3);
-            lo2 = lo3 < lo2 ? lo3 : lo2;
-        }
-        if (ovf || hi2 < 0 || hi2 > (INT64_MAX - 8) / bits - 1) return fail(PBH_ERR_INVALID, "payload addressing overflows");
-        if (add(L->hdr_bytes, ((hi2 + 1) * bits + 7) / 8) > L->blk_stride || ovf)
-            return fail(PBH_ERR_INVALID, "payload addressing overruns a block");
-        lo = lo2 < lo ? lo2 : lo;
-    }
-    if (lo < 0) return fail(PBH_ERR_INVALID, "payload addressing reaches before the payload");
-    const int64_t end_byte = add(add(mul(b1, L->blk_stride), L->hdr_bytes), pay_hi);
-    if (ovf) return fail(PBH_ERR_INVALID, "payload addressing overflows");
-    if ((uint64_t)end_byte > (uint64_t)raw_bytes)
-        return fail(PBH_ERR_INVALID, "raw buffer too short for the requested samples");
-    sp->b0 = b0;
-    sp->b1 = b1;
-    // the range starts at the lowest element read in the first block (a long time-major payload is one block:
-    // only the wanted samples travel), rounded down to 16 bytes
-    int64_t lo_first, hi_first;
-    reach(t_first, b1 > b0 ? L->blk_samples - 1 : t_last, &lo_first, &hi_first);
-    const int64_t skip = (L->hdr_bytes + lo_first * bits / 8) & ~(int64_t)15;
-    sp->off = (size_t)(b0 * L->blk_stride + skip);
-    sp->len = (size_t)end_byte - sp->off;
-    return PBH_OK;
+    const char* why = "bad argument";
+    const int rc = pbh_host::decode_span(L, first, nsample, nchan, npol, raw_bytes, sp, &why);
+    return rc == PBH_OK ? rc : fail(rc, why);
 }
 
 // draw: device copy of the raw stream from byte `skip` on (only offsets inside the checked span are formed)
@@ -2088,7 +2049,7 @@ static int build_mix_table(pbh_plan* p, int L, pbh_plan::MixTable* t, bool rows 
     int left = L;
     // radix 9 = 3 x 3 in registers: two levels per LDS round trip (PBH_MIX_SQUARE=0: radix 3 only, for A/B runs).  The same
     // for 25 = 5 x 5 needs more registers than two workgroups per CU leave (230-400 B/lane of scratch): not built.
-    static const bool square = [] { const char* e = getenv("PBH_MIX_SQUARE"); return e ? atoi(e) != 0 : true; }();
+    static const bool square = [] { const char* e = diag_env("PBH_MIX_SQUARE"); return e ? atoi(e) != 0 : true; }();
     if (square) while (left % 9 == 0) { t->radix[t->nstage++] = 9; left /= 9; }
     for (int r : {7, 5, 3}) while (left % r == 0) { if (t->nstage >= kMixMaxStages) return fail(PBH_ERR_UNSUPPORTED, "too many stages"); t->radix[t->nstage++] = r; left /= r; }
     while (left % 8 == 0) { t->radix[t->nstage++] = 8; left /= 8; }
@@ -2391,7 +2352,7 @@ static int create_plan(pbh_plan** out, int device, int64_t nsample, int nchan, i
             p->P = p->N1 / qmax;
     }
     {
-        const char* e = getenv("PBH_ROW2");
+        const char* e = diag_env("PBH_ROW2");
         const bool want = e ? atoi(e) != 0 : false;
 #ifdef PBH_F64
         p->perm_w = 0;
@@ -2567,7 +2528,7 @@ int pbh_chirp_generate(pbh_plan* p, double coeff_hz, double dt_s, const double* 
     // The fused row pass of such a plan reads the PHASE rows only.  The complex64 chirp (a float64 sincospi and 8 bytes written
     // per bin: 0.6 of the 0.8 ms this call took at config 2) is made when somebody asks for it -- pbh_chirp_download, i.e.
     // chirp_from_signal -- and not for every new DM of a search.  PBH_CHIRP_LAZY=0: always both.
-    static const bool lazy_on = [] { const char* e = getenv("PBH_CHIRP_LAZY"); return e ? atoi(e) != 0 : true; }();
+    static const bool lazy_on = [] { const char* e = diag_env("PBH_CHIRP_LAZY"); return e ? atoi(e) != 0 : true; }();
     p->chirp_lazy = lazy_on && p->has_phase && row_phase_enabled();
     if (p->chirp_lazy) cp.out = nullptr;
 #else
@@ -2782,7 +2743,7 @@ static void keep_pool_memory(int device) {
 // for every 16-byte cell (~nchan x).  Returns 1 when the geometry does not fit (the caller gathers directly).
 static int incoherent_two_pass(hipStream_t st, const void* in_dev, void* out_dev, int64_t nout, int nchan, int unit_words,
                                const int64_t* delay) {
-    static const bool on = [] { const char* e = getenv("PBH_INCOHERENT_2PASS"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_INCOHERENT_2PASS"); return e ? atoi(e) != 0 : true; }();
     if (!on || unit_words % 2 != 0) return 1;
     const int per = unit_words / 2;                  // 8-byte elements per (sample, channel) cell
     const int64_t S64 = (int64_t)nchan * per;
@@ -3007,7 +2968,7 @@ int pbh_dedisperse_layout(pbh_plan* p, const void* in_dev, int in_layout, int64_
 // 5.42 vs 4.86 and 6.53 vs 4.68 inverse (profiles/r03_stft_dedisp_fused.txt) -- the cost of 32- and 16-byte pieces is the
 // address work per byte in the CU's texture path, not a re-fetch across XCDs.  Default: two steps for those geometries.
 static bool stft_sibling_loop() {
-    static const bool on = [] { const char* e = getenv("PBH_STFT_SIBLINGS"); return e ? atoi(e) != 0 : false; }();
+    static const bool on = [] { const char* e = diag_env("PBH_STFT_SIBLINGS"); return e ? atoi(e) != 0 : false; }();
     return on;
 }
 
@@ -3038,7 +2999,7 @@ int PBH_FN(stft_dedisperse)(pbh_plan* p, const void* in_dev, int nperseg, int nc
     if (out_layout == PBH_LAYOUT_SERIES_MAJOR && !multipass)
         return fail(PBH_ERR_UNSUPPORTED, "series-major output needs a multi-pass power-of-two plan (nsample > one tile)");
 #ifndef PBH_F64
-    static const bool fuse_on = [] { const char* e = getenv("PBH_STFT_FUSE"); return e ? atoi(e) != 0 : true; }();
+    static const bool fuse_on = [] { const char* e = diag_env("PBH_STFT_FUSE"); return e ? atoi(e) != 0 : true; }();
     if (fuse_on && multipass && is_pow2(M) && M >= PBH_R && M * 16 <= kTilePoints) {
         const int F = kTilePoints / M;
         int SB = F / 16;
@@ -3119,7 +3080,7 @@ int PBH_FN(dedisperse_istft)(pbh_plan* p, const void* in_dev, int in_layout, int
     io.in_layout = in_layout;
     io.in_pitch = in_pitch;
 #ifndef PBH_F64
-    static const bool fuse_on = [] { const char* e = getenv("PBH_ISTFT_FUSE"); return e ? atoi(e) != 0 : true; }();
+    static const bool fuse_on = [] { const char* e = diag_env("PBH_ISTFT_FUSE"); return e ? atoi(e) != 0 : true; }();
     if (fuse_on && multipass && is_pow2(M) && M >= PBH_R && M * 16 <= kTilePoints) {
         const int F = kTilePoints / M;
         int SB = F / 16;
@@ -3543,7 +3504,7 @@ static int native_fft_plan(int device, int64_t n, int64_t batch, pbh_plan** out)
 }
 
 static bool native_fft_ok(int64_t n, int64_t batch) {
-    static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
     if (!on || batch > 65535 || n <= kTilePoints || n > (1LL << 28)) return false;
     if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
     int n1, n2, pp;   // 7-smooth lengths with rows the stand-alone row transform has, or with mixed-radix rows (mixed_kernels.hpp)
@@ -3683,7 +3644,7 @@ int pbh_real_to_complex(int device, void* hip_stream, const void* in_dev, void* 
 // forward stft through k_stft_fwd: power-of-two segments of at most tile/16 points whose tiles cover whole segments (S <=
 // tile/n) or whole channels of one segment (tile/n divides S and holds whole channels)
 static bool stft_linear_ok(int64_t n, int64_t S, int inner) {
-    static const bool on = [] { const char* e = getenv("PBH_STFT_LINEAR"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_STFT_LINEAR"); return e ? atoi(e) != 0 : true; }();
     if (!on || !is_pow2(n) || n < PBH_R || n * 32 > kTilePoints) return false;   // (at tile/16 the plain kernel is as fast or faster)
     const int64_t F = kTilePoints / n;
     if (S <= F) return true;
@@ -3691,13 +3652,13 @@ static bool stft_linear_ok(int64_t n, int64_t S, int inner) {
 }
 
 static bool stft_pair_enabled() {
-    static const bool on = [] { const char* e = getenv("PBH_STFT_PAIR"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_STFT_PAIR"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
 
 // contrib.stft / istft with native segment lengths beyond one tile: the segments are the batch
 static bool stft_native_ok(int64_t n, int64_t nseg, int64_t S) {
-    static const bool on = [] { const char* e = getenv("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
+    static const bool on = [] { const char* e = diag_env("PBH_NATIVE_FFT"); return e ? atoi(e) != 0 : true; }();
     if (!on || n <= kTilePoints || n > (1LL << 27) || nseg * S > 0x7fffffffLL || nseg * S * (n / kTilePoints + 1) / 64 > 0x7fffffffLL)
         return false;
     if ((is_pow2(n) && n >= 2 * (int64_t)kTilePoints) || native_odd_factor(n) != 0) return true;
@@ -4023,15 +3984,6 @@ static int64_t stream_epoch_max() {
     const int64_t v = e ? atoll(e) : 0;
     return v >= 1 && v <= 64 ? v : 0;   // 0: not forced
 }
-static int64_t stream_epoch_chunks(size_t first_bytes, size_t step_bytes, int64_t nchunk) {
-    const size_t cap = stream_window_cap();
-    int64_t B = 1;
-    if (step_bytes == 0) B = 64;
-    else if (cap > first_bytes) B = 1 + (int64_t)((cap - first_bytes) / step_bytes);
-    B = B > 64 ? 64 : B;
-    if (stream_epoch_max()) B = stream_epoch_max();
-    return B > nchunk ? nchunk : B;
-}
 }  // namespace
 
 // Detected output of the streaming calls (pbh_plan_stream_detect): every chunk ends in the fused detect tail and what goes
@@ -4084,15 +4036,17 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsampl
     const int64_t N = p->N, hop = p->stop - p->start;
     if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
     if (total_nsample < N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
-    const int64_t nchunk = (total_nsample - N) / hop + 1;
     HIPCHECK(hipSetDevice(p->device));
     const size_t row = sizeof(cf) * (size_t)p->S;
-    const size_t out_bytes = stream_out_bytes(p), step = row * (size_t)hop, keep = row * (size_t)(N - hop);
+    // the schedule (epochs, windows, what every chunk uploads and takes over): host_sched.hpp
+    pbh_host::RowStream sched;
+    if (!pbh_host::row_stream(N, hop, total_nsample, row, stream_window_cap(), stream_epoch_max(), &sched))
+        return fail(PBH_ERR_INVALID, "bad stream geometry");
+    const int64_t nchunk = sched.nchunk;
+    const size_t out_bytes = stream_out_bytes(p);
     const size_t host_in_bytes = row * (size_t)total_nsample, host_out_bytes = out_bytes * (size_t)nchunk;
-    // a chunk starts j*hop rows into its window: the layout kernels want that on a 16-byte boundary, else one chunk per epoch
-    const int64_t B = step % 16 == 0 ? stream_epoch_chunks(row * (size_t)N, step, nchunk) : 1;
-    const size_t win_bytes = row * (size_t)(N + (B - 1) * hop);
-    const int nwin = nchunk > B ? 2 : 1;
+    const size_t win_bytes = sched.win_bytes;
+    const int nwin = sched.nwin;
 
     void* dwin[2] = {nullptr, nullptr};
     void* dout[2] = {nullptr, nullptr};
@@ -4114,31 +4068,30 @@ int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsampl
         rig.ok(hipEventRecord(rig.t[2], rig.s_in), "hipEventRecord");
         rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.t[0], 0), "hipStreamWaitEvent");
         for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const int64_t e = k / B, j = k - e * B;
-            const int w = (int)(e & 1) % nwin, b = (int)(k & 1);
+            const pbh_host::RowChunk c = pbh_host::row_chunk(sched, k);
+            const int64_t e = c.epoch, j = c.j;
+            const int w = c.win, b = (int)(k & 1);
             char* win = (char*)dwin[w];
             char* dst = (char*)host_out + (size_t)k * out_bytes;
             // upload the rows this chunk adds: all N for the first chunk, afterwards rows [(k-1)*hop + N, k*hop + N)
             if (j == 0 && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
-            const size_t have = k == 0 ? 0 : keep;
-            const size_t add = row * (size_t)N - have;
-            rig.ok(hipMemcpyAsync(win + (size_t)j * step + have, (const char*)host_in + (size_t)k * step + have, add,
-                                  hipMemcpyHostToDevice, rig.s_in), "hipMemcpyAsync H2D");
-            stats[0] += (double)add;
+            rig.ok(hipMemcpyAsync(win + c.up_dst, (const char*)host_in + c.up_src, c.up_bytes, hipMemcpyHostToDevice, rig.s_in),
+                   "hipMemcpyAsync H2D");
+            stats[0] += (double)c.up_bytes;
             rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
             rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
             if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
             rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
-            if (j == 0 && k > 0) {   // a new epoch: the shared rows come from the tail of the other window, which is then free
-                if (keep > 0)
-                    rig.ok(hipMemcpyAsync(win, (const char*)dwin[w ^ 1] + (size_t)B * step, keep, hipMemcpyDeviceToDevice, rig.s_cmp),
+            if (c.handover) {   // a new epoch: the shared rows come from the tail of the other window, which is then free
+                if (c.ho_bytes > 0)
+                    rig.ok(hipMemcpyAsync(win, (const char*)dwin[w ^ 1] + c.ho_src, c.ho_bytes, hipMemcpyDeviceToDevice, rig.s_cmp),
                            "hipMemcpyAsync D2D");
-                stats[7] += (double)keep;
+                stats[7] += (double)c.ho_bytes;
                 rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
             }
             if (rc == PBH_OK) {
                 const DetectTail tail = stream_tail(p, dout[b]);
-                auto steps = build_steps(p, (const cf*)(win + (size_t)j * step), tail.out ? nullptr : (cf*)dout[b], tail);
+                auto steps = build_steps(p, (const cf*)(win + c.win_off), tail.out ? nullptr : (cf*)dout[b], tail);
                 rc = run_steps(steps, rig.s_cmp);
             }
             rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
@@ -4182,37 +4135,22 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
     if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
     if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
     const int64_t nchunk = (total_nsample - p->N) / hop + 1;
-    // spans of all chunks up front: bounds checks, the epochs and the size of the device windows
-    std::vector<DecodeSpan> spans((size_t)nchunk);
-    for (int64_t k = 0; k < nchunk; ++k)
-        PBHCHECK(decode_span(L, first + k * hop, p->N, p->nchan, p->npol, raw_bytes, &spans[(size_t)k]));
-    auto end_of = [&](int64_t k) { return spans[(size_t)k].off + spans[(size_t)k].len; };
-    // chunk k extends what chunk k-1 left on the device when its span starts inside (or right behind) that span and ends no earlier
-    auto extends = [&](int64_t k) {
-        return k > 0 && spans[(size_t)k].off >= spans[(size_t)k - 1].off && spans[(size_t)k].off <= end_of(k - 1) && end_of(k) >= end_of(k - 1);
-    };
-    struct Epoch { int64_t k0; size_t base; };
-    std::vector<Epoch> epochs;
-    std::vector<int> epoch_of((size_t)nchunk);
-    size_t win_bytes = 0;
+    // spans of all chunks up front: bounds checks, then the epochs and the size of the device windows (host_sched.hpp)
+    pbh_host::SpanStream sched;
     {
-        const int64_t cap_chunks = stream_epoch_max() ? stream_epoch_max() : 64;
-        const size_t cap = stream_epoch_max() ? SIZE_MAX : stream_window_cap();
-        for (int64_t k = 0; k < nchunk; ++k) {
-            const bool fresh = epochs.empty() || !extends(k) || k - epochs.back().k0 >= cap_chunks ||
-                               end_of(k) - epochs.back().base > cap;
-            if (fresh) epochs.push_back({k, spans[(size_t)k].off - spans[(size_t)k].off % 16});
-            epoch_of[(size_t)k] = (int)epochs.size() - 1;
-            const size_t need = end_of(k) - epochs.back().base;
-            win_bytes = need > win_bytes ? need : win_bytes;
-        }
+        std::vector<DecodeSpan> spans((size_t)nchunk);
+        for (int64_t k = 0; k < nchunk; ++k)
+            PBHCHECK(decode_span(L, first + k * hop, p->N, p->nchan, p->npol, raw_bytes, &spans[(size_t)k]));
+        pbh_host::span_stream(std::move(spans), stream_epoch_max() ? stream_epoch_max() : 64,
+                              stream_epoch_max() ? SIZE_MAX : stream_window_cap(), &sched);
     }
+    const size_t win_bytes = sched.win_bytes;
     HIPCHECK(hipSetDevice(p->device));
     const bool sm = !(p->bsL || p->mixed || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
                       p->N >= (1LL << 31)) && p->S > 1;
     const size_t row = sizeof(cf) * (size_t)p->S;
     const size_t out_bytes = stream_out_bytes(p), host_out_bytes = out_bytes * (size_t)nchunk;
-    const int nwin = epochs.size() > 1 ? 2 : 1;
+    const int nwin = sched.nwin;
 
     void* dwin[2] = {nullptr, nullptr};
     void* dout[2] = {nullptr, nullptr};
@@ -4247,36 +4185,33 @@ int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_byte
             io.in_pitch = p->N;
         }
         for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const int e = epoch_of[(size_t)k];
-            const Epoch& ep = epochs[(size_t)e];
-            const bool head = k == ep.k0;                       // first chunk of its epoch
-            const int w = (e & 1) % nwin, b = (int)(k & 1);
+            const pbh_host::SpanChunk c = pbh_host::span_chunk(sched, k);
+            const int e = c.epoch;
+            const bool head = c.head;                           // first chunk of its epoch
+            const int w = c.win, b = (int)(k & 1);
             unsigned char* win = (unsigned char*)dwin[w];
             char* dst = (char*)host_out + (size_t)k * out_bytes;
-            // file bytes [lo, end_of(k)) are new to the device; [ep.base, lo) of a new epoch come out of the other window
-            const bool reuse = extends(k);
-            const size_t lo = reuse ? end_of(k - 1) : spans[(size_t)k].off;
+            // file bytes [up_lo, up_hi) are new to the device; [base, up_lo) of a new epoch come out of the other window
             if (head && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
-            if (end_of(k) > lo) {
-                rig.ok(hipMemcpyAsync(win + (lo - ep.base), (const char*)host_raw + lo, end_of(k) - lo, hipMemcpyHostToDevice, rig.s_in),
+            if (c.up_hi > c.up_lo) {
+                rig.ok(hipMemcpyAsync(win + (c.up_lo - c.base), (const char*)host_raw + c.up_lo, c.up_hi - c.up_lo, hipMemcpyHostToDevice, rig.s_in),
                        "hipMemcpyAsync H2D");
-                stats[0] += (double)(end_of(k) - lo);
+                stats[0] += (double)(c.up_hi - c.up_lo);
             }
             rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
             rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
             if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
             rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
             if (head && k > 0) {
-                if (reuse && lo > ep.base) {
-                    const Epoch& prev = epochs[(size_t)e - 1];
-                    rig.ok(hipMemcpyAsync(win, (const unsigned char*)dwin[w ^ 1] + (ep.base - prev.base), lo - ep.base,
-                                          hipMemcpyDeviceToDevice, rig.s_cmp), "hipMemcpyAsync D2D");
-                    stats[7] += (double)(lo - ep.base);
+                if (c.handover) {
+                    rig.ok(hipMemcpyAsync(win, (const unsigned char*)dwin[w ^ 1] + c.ho_src, c.ho_bytes, hipMemcpyDeviceToDevice, rig.s_cmp),
+                           "hipMemcpyAsync D2D");
+                    stats[7] += (double)c.ho_bytes;
                 }
                 rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
             }
             if (rc == PBH_OK)
-                rc = decode_launch(win, (int64_t)ep.base, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
+                rc = decode_launch(win, (int64_t)c.base, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
                                    sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, rig.s_cmp);
             if (rc == PBH_OK) {
                 const DetectTail tail = stream_tail(p, dout[b]);

@@ -412,21 +412,32 @@ int pbh_node_share_alloc(int device, size_t bytes, void** dev_ptr, int* fd_out) 
 }
 
 int pbh_node_share_import(int device, int fd, size_t bytes, void** dev_ptr) {
+    if (dev_ptr) *dev_ptr = nullptr;   // (also on the error paths: found by tests/sanitizer/api_nodevice_test.cpp)
     if (!dev_ptr || fd < 0 || bytes == 0) return fail_here(PBH_ERR_INVALID, "pbh_node_share_import: bad argument");
-    *dev_ptr = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail("hipSetDevice", e);
     hipMemAllocationProp prop{};
     const size_t size = shared_round(device, bytes, &prop);
     hipMemGenericAllocationHandle_t h;
     // The HIP runtimes in use disagree about `osHandle`: 7.0 (the one torch 2.10+rocm7.0 bundles and loads first) takes a POINTER to
-    // the descriptor and dies with SIGSEGV on CUDA's form, the descriptor's value cast to a pointer; 7.2 takes the value.  A pointer
-    // handed to a value-taking runtime is merely a bad descriptor number (an error), the reverse is a crash: pointer form first.
+    // the descriptor and dies with SIGSEGV on CUDA's form, the descriptor's value cast to a pointer; 7.2 takes the value.  The form
+    // is chosen from the version of the runtime that is actually loaded (hipRuntimeGetVersion: major * 10^7 + minor * 10^5 + patch):
+    //   7.0.x      pointer form ONLY (the value form would be dereferenced: a crash, never an error code)
+    //   >= 7.2     value form, then the pointer form as a fallback (a pointer handed to a value-taking runtime is merely a bad
+    //              descriptor number: an error)
+    //   otherwise  (7.1, older, unreadable) the round-3 probe: pointer form first, value form on error
+    int rv = 0;
+    if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+    const int major = rv / 10000000, minor = (rv / 100000) % 100;
+    const bool value_first = major > 7 || (major == 7 && minor >= 2);
+    const bool pointer_only = major == 7 && minor == 0;
     int fdv = fd;
-    e = hipMemImportFromShareableHandle(&h, (void*)&fdv, hipMemHandleTypePosixFileDescriptor);
-    if (e != hipSuccess) {
+    void* const as_pointer = (void*)&fdv;
+    void* const as_value = (void*)(uintptr_t)fd;
+    e = hipMemImportFromShareableHandle(&h, value_first ? as_value : as_pointer, hipMemHandleTypePosixFileDescriptor);
+    if (e != hipSuccess && !pointer_only) {
         (void)hipGetLastError();
-        e = hipMemImportFromShareableHandle(&h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+        e = hipMemImportFromShareableHandle(&h, value_first ? as_pointer : as_value, hipMemHandleTypePosixFileDescriptor);
     }
     if (e != hipSuccess) return hip_fail("pbh_node_share_import: hipMemImportFromShareableHandle", e);
     const int rc = shared_map(device, h, size, dev_ptr);

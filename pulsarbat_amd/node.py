@@ -172,16 +172,37 @@ def _exchange_fds(group, my_fds, timeout=60.0):
     import threading
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    path, server, private = None, None, None
+    path, server, private, setup_err = None, None, None, None
     if my_fds:
-        private = tempfile.mkdtemp(prefix="pbh_gather_")   # mode 0700: only this user's processes can reach the socket
-        path = os.path.join(private, "fds.sock")
-        server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        server.bind(path)
-        server.listen(world)
-        server.settimeout(timeout)
+        # local, fallible work (a TMPDIR beyond sun_path's 108 bytes, an unwritable directory): a failure here must not
+        # keep this rank out of the collective below -- it travels in it, and every rank raises after it
+        try:
+            if os.environ.get("PBH_TEST_FDS_BIND_FAIL") == str(rank):
+                raise OSError("injected bind failure (PBH_TEST_FDS_BIND_FAIL)")
+            private = tempfile.mkdtemp(prefix="pbh_gather_")   # mode 0700: only this user's processes can reach the socket
+            path = os.path.join(private, "fds.sock")
+            server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            server.bind(path)
+            server.listen(world)
+            server.settimeout(timeout)
+        except Exception as exc:
+            setup_err = f"rank {rank}: {exc!r}"
+            if server is not None:
+                server.close()
+                server = None
+            path = None
     paths = [None] * world
-    dist.all_gather_object(paths, (path, len(my_fds)), group=group)
+    dist.all_gather_object(paths, (path, len(my_fds), setup_err), group=group)
+    bad = [e for _, _, e in paths if e]
+    if bad:
+        if private is not None:
+            for undo, what in ((os.unlink, os.path.join(private, "fds.sock")), (os.rmdir, private)):
+                try:
+                    undo(what)
+                except OSError:
+                    pass
+        raise _hip.HipError("descriptor exchange could not be set up: " + "; ".join(bad))
+    paths = [(pth, nfd) for pth, nfd, _ in paths]
     errors = []
 
     def serve():
@@ -414,7 +435,12 @@ class ChannelGather:
         except Exception as exc:
             err = exc
         self._runs += 1
-        if self._agree(err is not None):           # ... and so have everybody else's
+        try:
+            failed = self._agree(err is not None)      # ... and so have everybody else's
+        except BaseException:
+            self._broken = True                        # the ranks did not agree: close() must not enter a collective alone
+            raise
+        if failed:
             raise GatherError(f"gather run failed on rank {self.rank}: {err!r}" if err is not None
                               else "gather run failed on another rank") from err
         if self.own is None:
@@ -442,9 +468,10 @@ class ChannelGather:
             self.own = None
 
     def close(self):
-        """Collective: unmap the peers' chunks, agree that everybody has, free the own chunks.  After a failure that the
-        ranks did not agree on (``_broken``) the collective is skipped and the own chunks are left to process exit --
-        a leak, not a hang, and no peer is left with a dangling mapping."""
+        """Collective: unmap the peers' buffers, agree that everybody has, free the own ones.  After a failure that the
+        ranks did not agree on (``_broken``: the closing all-reduce of a run itself raised) the collective is skipped and the
+        own buffers are NOT freed here -- a peer may still map them; they go when the SharedBuffer / NodeBuffer objects are
+        collected (their ``__del__``) or the process exits: a late free, not a hang."""
         if getattr(self, "_closed", False):
             return
         self._closed = True

@@ -27,40 +27,57 @@ from .core import BasebandSignal
 
 __all__ = ["channel_slice", "shard_signal", "coherent_dedispersion_sharded", "dedisperse_detect_sharded", "release_gathers"]
 
-# ChannelGather objects by (thread, geometry, group, mode, root), next to the plan cache (transforms.dedispersion._PLANS):
-# a stream of blocks through coherent_dedispersion_sharded(gather=...) sets the destination chunks and their peer mappings
-# up ONCE.  Construction and release are collective, and every rank of a group makes the same sequence of calls, so the
-# ranks' caches stay in step.
+# ChannelGather objects by (nout, npol, dtype, device, group, mode, root), next to the plan cache (transforms.dedispersion._PLANS):
+# a stream of blocks through coherent_dedispersion_sharded(gather=...) sets the destination buffers and their peer mappings up
+# ONCE.  Construction and release are collective, so a rank may use its cached gather only if EVERY rank has one for the
+# call: the ranks agree on that with one small all-reduce per call (a rank-local key can hit on one rank and miss on another --
+# a thread identity reused by one process only, a channel count that changed on some ranks only -- and the missing rank's
+# set-up collectives would then meet the others' run).  The key holds nothing that differs between ranks except the device.
 _GATHERS = {}
 _GATHERS_LOCK = threading.Lock()
 _GATHER_CACHE_SIZE = 4
 
 
+def _all_hit(group, dev, hit):
+    """Collective: True if every rank of the group found a usable cached gather (one MIN all-reduce of a flag)."""
+    import torch
+    import torch.distributed as dist
+    cdev = torch.device("cuda", int(dev)) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if hit else 0], dtype=torch.int32, device=cdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
 def _gather_for(plan, nchan, npol, dtype, dev, group, mode, root):
     from .node import ChannelGather
-    key = (threading.get_ident(), plan.nout, int(nchan), int(npol), np.dtype(dtype).str, int(dev), id(group) if group is not None else None,
-           mode, int(root))
+    key = (plan.nout, int(npol), np.dtype(dtype).str, int(dev), id(group) if group is not None else None, mode, int(root))
     with _GATHERS_LOCK:
         g = _GATHERS.get(key)
-    if g is None:
+    usable = g is not None and g.nchan_local == int(nchan) and not getattr(g, "_closed", False)
+    if not _all_hit(group, dev, usable):
+        # some rank has to build: everybody builds (and everybody first closes what it had for the key, in step)
+        if g is not None:
+            with _GATHERS_LOCK:
+                _GATHERS.pop(key, None)
+            g.close()
         g = ChannelGather(plan.nout, nchan, npol, dtype, dev, group=group, mode=mode, root=root)
         stale = []
         with _GATHERS_LOCK:
             _GATHERS[key] = g
-            mine = [k for k in _GATHERS if k[0] == key[0]]
-            while len(mine) > _GATHER_CACHE_SIZE:      # oldest first; the same choice on every rank
+            mine = [k for k in _GATHERS if k[4] == key[4]]
+            while len(mine) > _GATHER_CACHE_SIZE:      # oldest first: every rank built them in the same order
                 stale.append(_GATHERS.pop(mine.pop(0)))
         for old in stale:
             old.close()
     return key, g
 
 
-def release_gathers():
-    """Collective: close the calling thread's cached gathers (destination chunks, peer mappings).  Call it on every rank of
-    the group, e.g. before ``destroy_process_group``; the memory is otherwise held for re-use by later calls."""
-    me = threading.get_ident()
+def release_gathers(group=None):
+    """Collective: close the cached gathers of ``group`` (all groups when None): destination buffers, peer mappings.  Call it
+    on every rank of the group, e.g. before ``destroy_process_group``; the memory is otherwise held for re-use by later calls."""
+    gid = id(group) if group is not None else None
     with _GATHERS_LOCK:
-        stale = [_GATHERS.pop(k) for k in [k for k in _GATHERS if k[0] == me]]   # insertion order: the same on every rank
+        stale = [_GATHERS.pop(k) for k in [k for k in _GATHERS if group is None or k[4] == gid]]   # insertion order: the same on every rank
     for g in stale:
         g.close()
 
@@ -273,16 +290,25 @@ def _gather_channels(shard, band_min, band_max, group, root=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [None] * world
     dist.all_gather_object(sizes, int(t.shape[1]), group=group)
-    # channel-major contiguous pieces so every rank contributes one flat buffer
-    mine = torch.view_as_real(t.transpose(0, 1).contiguous())
+    sizes = [int(n) for n in sizes]
+    # channel-major contiguous pieces so every rank contributes one flat buffer; ragged shards (nchan % world != 0) are
+    # padded to the largest one -- gloo's all_gather / gather want equal sizes -- and trimmed after the collective
+    piece = torch.view_as_real(t.transpose(0, 1).contiguous())
+    nmax = max(sizes)
+    mine = piece
+    if piece.shape[0] != nmax:
+        mine = torch.zeros((nmax,) + tuple(piece.shape[1:]), dtype=piece.dtype)
+        mine[:piece.shape[0]] = piece
+    bufs = None
     if root is None or rank == root:
-        bufs = [torch.empty((int(n),) + tuple(mine.shape[1:]), dtype=mine.dtype) for n in sizes]
+        bufs = [torch.empty_like(mine) for _ in sizes]
     if root is None:
         dist.all_gather(bufs, mine, group=group)
     else:
         dist.gather(mine, bufs if rank == root else None, dst=_global_rank(group, root), group=group)
         if rank != root:
             return None
+    bufs = [b[:n] for b, n in zip(bufs, sizes)]
     full = torch.view_as_complex(torch.cat(bufs, dim=0)).transpose(0, 1).contiguous()
     center = (band_min + band_max) / 2
     return type(shard).like(shard, full.numpy(), center_freq=center, freq_align="center")

@@ -141,3 +141,158 @@ def test_user_chirp_scatter_world2():
         assert got.shape == (256, hi - lo, 2) and np.array_equal(got, full[:, lo:hi])
         assert np.array_equal(got1, full[:, :1])
         assert vec.shape == (256, 1) and np.array_equal(vec[:, 0], full[:, 0, 0])
+
+
+def _run_world(target, world=2, args=()):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda r: r[0])
+
+
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pulsarbat_amd.transforms import dedispersion as dd
+    dd._plan_for = _oracle_plan_for
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = orc.synthetic_block((2048, 5, 2), 9)        # 5 channels over 2 ranks: 3 + 2
+    z = pb.DualPolarizationSignal(x, sample_rate=SR * u.Hz, center_freq=FC * u.Hz, pol_type="linear")
+    zl = shard.shard_signal(z, world, rank)
+    kw = dict(band_min=z.min_freq, band_max=z.max_freq, ref_freq=z.center_freq, device=0)
+    full = shard.coherent_dedispersion_sharded(zl, pb.DM(DM), gather=True, **kw)
+    at_root = shard.coherent_dedispersion_sharded(zl, pb.DM(DM), gather="root", root=0, **kw)
+    q.put((rank, np.asarray(full), None if at_root is None else np.asarray(at_root)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_host_gather_world2():
+    """nchan % world != 0: the host-side all_gather / gather get equal-sized (padded) pieces (gloo rejects unequal ones)."""
+    res = _run_world(_ragged_worker)
+    x = orc.synthetic_block((2048, 5, 2), 9)
+    want, _, _ = orc.coherent_dedispersion(x, DM, SR, FC)
+    for rank, full, at_root in res:
+        assert full.shape == want.shape and np.allclose(full, want, rtol=0, atol=1e-6)
+        assert (at_root is None) == (rank != 0)
+        if at_root is not None:
+            assert np.array_equal(at_root, full)
+
+
+class _FakeGather:
+    """Stands in for node.ChannelGather (device memory) in the cache test: counts its collectives."""
+    built = 0
+
+    def __init__(self, nout, nchan_local, npol, dtype, device, group=None, mode="all", root=0):
+        import torch.distributed as dist
+        counts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(counts, int(nchan_local), group=group)       # the real constructor's first collective
+        self.counts, self.nchan_local, self._closed = counts, int(nchan_local), False
+        _FakeGather.built += 1
+
+    def close(self):
+        import torch
+        import torch.distributed as dist
+        if not self._closed:
+            self._closed = True
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32))              # the real close() is collective too
+
+
+class _P:
+    nout = 100
+
+
+def _cache_worker(rank, world, port, q):
+    import threading
+    import torch.distributed as dist
+    from pulsarbat_amd import node
+    node.ChannelGather = _FakeGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+
+    def call(nchan):
+        _, g = shard._gather_for(_P(), nchan, 2, np.complex64, 0, None, "all", 0)
+        log.append((nchan, tuple(g.counts), _FakeGather.built))
+        return g
+
+    g1 = call(2)                       # built on both ranks
+    g2 = call(2)                       # hit on both ranks
+    assert g2 is g1
+    # 4 -> 5 channels over two ranks: (2, 2) -> (3, 2): only rank 0's local count changes -- rank 1's key would still hit
+    g3 = call(3 if rank == 0 else 2)
+    assert g3 is not g1 and g1._closed
+    # the call moves to a fresh thread on ONE rank only (thread identities are not part of the key any more)
+    out = []
+    if rank == 1:
+        th = threading.Thread(target=lambda: out.append(call(2)))
+        th.start()
+        th.join()
+    else:
+        out.append(call(3))
+    assert out[0] is g3
+    shard.release_gathers()
+    q.put((rank, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_cache_is_agreed_between_ranks_world2():
+    """a cache hit on one rank and a miss on another must not happen (the miss's set-up collectives would
+    meet the hit's run).  The ranks agree on hit / miss with one all-reduce; if anybody misses, everybody rebuilds."""
+    res = _run_world(_cache_worker)
+    for rank, log in res:
+        assert [b for _, _, b in log] == [1, 1, 2, 2]
+        assert log[2][1] == (3, 2) and log[3][1] == (3, 2)
+
+
+def _fds_worker(rank, world, port, q, fail_rank):
+    import torch.distributed as dist
+    from pulsarbat_amd import node, _hip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PBH_TEST_FDS_BIND_FAIL"] = str(fail_rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, w = os.pipe()
+    err = None
+    try:
+        node._exchange_fds(None, [r] if rank == fail_rank else [], timeout=10.0)     # root mode: one rank serves
+    except _hip.HipError as exc:
+        err = str(exc)
+    # ... and the ranks are still in step: the next collective completes
+    import torch
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    os.close(r)
+    os.close(w)
+    # without the injected failure the exchange works: every rank gets rank 0's descriptor
+    os.environ.pop("PBH_TEST_FDS_BIND_FAIL")
+    r2, w2 = os.pipe()
+    got = node._exchange_fds(None, [r2] if rank == 0 else [], timeout=10.0)
+    ok = (rank == 0 and got == {}) or (rank != 0 and list(got) == [0] and len(got[0]) == 1)
+    for fds in got.values():
+        for fd in fds:
+            os.close(fd)
+    os.close(r2)
+    os.close(w2)
+    q.put((rank, err, float(t.item()), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fd_exchange_set_up_failure_raises_on_all_ranks_world2():
+    """ADVICE round 3 / VERDICT item 4b: a rank-local failure before the exchange's collective (bind on a bad path) used to
+    leave that rank in the next all-reduce while the others sat in all_gather_object.  It now travels in the collective."""
+    res = _run_world(_fds_worker, args=(0,))
+    for rank, err, total, ok in res:
+        assert err is not None and "rank 0" in err and "injected bind failure" in err
+        assert total == 2.0 and ok
