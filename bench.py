@@ -177,8 +177,8 @@ def extra_configs3_stream(total_log2=26):
               "input_Msamples_per_s": float(total) * nchan * npol / ms_fb / 1e3}
     except Exception as exc:   # an extra of an extra
         fb = {"error": repr(exc)}
-    return {"filterbank_stream": fb, "workload": "configs[3] bounded: 2^%d samples x 8 x 2 in 2^22-sample chunks, hop %d, %d chunks (full config: 2^28, "
-                        "430 chunks)" % (total_log2, hop, st["nchunk"]),
+    return {"filterbank_stream": fb, "workload": ("configs[3] FULL SIZE" if total_log2 == 28 else "configs[3] bounded") +
+                        ": 2^%d samples x 8 x 2 in 2^22-sample chunks, hop %d, %d chunks (full config: 2^28, 430 chunks)" % (total_log2, hop, st["nchunk"]),
             "ms_total": ms, "input_GB": x.nbytes / 1e9, "h2d_GB": st["h2d_bytes"] / 1e9, "d2h_GB": st["d2h_bytes"] / 1e9,
             "h2d_GBps": st["h2d_GBps"], "d2h_GBps": st["d2h_GBps"], "kernel_ms": st["kernel_ms"],
             "overlap_efficiency": st["overlap_efficiency"],
@@ -370,18 +370,24 @@ def main():
     dom_name, dom_ms = max(kern, key=lambda kv: kv[1])
     dom_bytes = alg.get(dom_name, 16.0) * samples_gpu   # an unlisted pass (k_radix_*, k_pad ...) moves 8 r + 8 w
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, prof_us = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name)
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom_name)
+            prof_us = (tj.get("_kernel_us") or {}).get(dom_name)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": "stored: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                   "command (tools/prof.sh); not collected in this run",
-                "alg_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms}
+                "alg_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
+                # the same fraction from the TRACKED rocprofv3 summary (profiles/traffic.json "_kernel_us": mean duration of
+                # this kernel in the kernel-trace pass of tools/prof.sh): reproducible from the committed files alone
+                "frac_rocprof": None if not prof_us else dom_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "rocprof_us_per_launch": prof_us}
     total_kernel_ms = sum(ms for _, ms in kern)
     path_bytes = info["alg_bytes_per_sample"] * samples_gpu  # 68 B/sample accounting figure
     # what the five passes really move, and what that costs at the chip's own copy rate, measured now
@@ -439,12 +445,24 @@ def main():
         if world == 1 and not args.no_extras and args.log2n == 24:
             del x, y, z_local
             torch.cuda.empty_cache()
-            for key, fn in (("configs4_share", extra_configs4_share), ("configs3_stream", extra_configs3_stream)):
+            extras = [("configs4_share", extra_configs4_share), ("configs3_stream", extra_configs3_stream)]
+            # BASELINE configs[3] at FULL size (2^28 samples x 8 x 2 in 2^22-sample chunks = 430 chunks: 34.4 GB in, 33.9 GB out, both
+            # page-locked for the call) when the host has the memory for it; the bounded 2^26 run above stays as the fallback
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available
+            except Exception:
+                avail = 0
+            if avail >= 110e9:
+                extras.append(("configs3_stream_full", lambda: extra_configs3_stream(28)))
+            for key, fn in extras:
                 try:
                     result[key] = fn()
                 except Exception as exc:   # extras never cost the main line
                     result[key] = {"error": repr(exc)}
                 mark(f"extra {key} done")
+            if avail < 110e9:
+                result["configs3_stream_full"] = {"skipped": "host memory available %.0f GB < 110 GB" % (avail / 1e9)}
         if world == 1 and not args.no_cpu:
             try:
                 result["cpu_baseline"] = cpu_baseline()

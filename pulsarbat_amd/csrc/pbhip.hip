@@ -259,12 +259,13 @@ struct pbh_plan {
     size_t cls_len = 0;
     struct ClsEntry { const void* ptr = nullptr; size_t bytes = 0; int cls = -1; };
     ClsEntry cls_cache[8];
-    int cls_next = 0;
+    int cls_next = 0, cls_probes = 0;   // (at most kClassProbes probe copies per plan: a caller with ever new arrays is not probed for ever)
     // four-pass schedule: which of the two work buffers holds the Q4 intermediate, per (input, output) pair -- decided by
     // timing both assignments on the first call with that pair (fd4_roles)
     struct RoleEntry { const void* in = nullptr; const void* out = nullptr; int swap = 0; };
     RoleEntry role_cache[8];
     int role_next = 0;
+    int role_tunes = 0, role_last = 0;   // pairs timed so far (at most kRoleTunes per plan), the last decision
     int fd4_force = -1;   // >= 0 while fd4_roles times an assignment
     real* det_part = nullptr;  // detect tail fused into the inverse column pass: per-tile power sums (ColpParams::det_part),
     size_t det_bytes = 0;      // S * N / 16 floats + S * N1 * (N2 / nscrunch) for the groups with a scrunch boundary
@@ -1042,6 +1043,9 @@ static int buffer_class(pbh_plan* p, const void* ptr, size_t bytes) {
     if (!class_probing() || !ptr || !p->work || !p->work2 || p->cls_t_diff <= 0 || bytes < p->cls_len) return -1;
     for (auto& e : p->cls_cache)
         if (e.ptr == ptr && e.bytes == bytes) return e.cls;
+    constexpr int kClassProbes = 8;
+    if (p->cls_probes >= kClassProbes) return -1;
+    ++p->cls_probes;
     float t1 = 0.f, t2 = 0.f;
     int cls = -1;
     if (probe_copy_pair(ptr, p->work, p->work2, p->cls_len, p->stream, &t1, &t2)) {
@@ -1229,9 +1233,14 @@ static int fd4_roles(pbh_plan* p, const cf* in, cf* out, const DetectTail& tail,
         if (e.in == in && e.out == okey && e.in) return e.swap;
     // bit 0: the Q4 intermediate lives in work2 (else in work); bit 1: the inverse column pass runs out of place, back into
     // the buffer the Q4 intermediate left (else in place on the planar one)
-    int swap = 0;
+    // A caller that hands over a fresh output array at every call (results kept in a list) shows a new pair each time: only
+    // the first kRoleTunes pairs of a plan are timed (8 extra runs each), later ones take the last decision as it stands.
+    constexpr int kRoleTunes = 3;
+    int swap = p->role_last;
     const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
-    if (class_probing() && bytes >= ((size_t)1 << 30) && p->stop > p->start) {
+    if (class_probing() && bytes >= ((size_t)1 << 30) && p->stop > p->start && p->role_tunes < kRoleTunes) {
+        ++p->role_tunes;
+        swap = 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         float best[4] = {-1.f, -1.f, -1.f, -1.f};
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
@@ -1262,6 +1271,7 @@ static int fd4_roles(pbh_plan* p, const cf* in, cf* out, const DetectTail& tail,
     e.in = in;
     e.out = okey;
     e.swap = swap;
+    p->role_last = swap;
     return swap;
 }
 #endif

@@ -10,6 +10,10 @@ def step(kname):
     k = _re.sub(r"(void )?pbh(32|64)?::", "", kname)
     if k.startswith("k_col<") or k.startswith("k_colq<"):
         return "k_col_inv" if k.split(",")[1].strip().startswith("1") else "k_col_fwd"
+    if k.startswith("k_colfd<"):     # four-pass schedule (fd4_kernels.hpp)
+        return "k_col_fwd"
+    if k.startswith("k_rowq16<"):
+        return "k_row_fused"
     for a, b in NAMES.items():
         if k.startswith(a):
             return b
@@ -29,6 +33,19 @@ for kname, c in acc.items():
     write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
     res[step(kname)] += (2.0 * fetch + write) * 1024.0
 res = dict(res)
+# mean kernel durations of the trace pass of the same prof.sh run (microseconds per launch, summed per step): what
+# bench.py's roofline.frac_rocprof divides the algorithmic bytes by
+dur = collections.defaultdict(list)
+files = sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+for f in files[-1:]:
+    for r in csv.DictReader(open(f)):
+        if step(r["Kernel_Name"]):
+            dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+kus = collections.defaultdict(float)
+for kname, v in dur.items():
+    v = sorted(v)[len(v) // 10:]          # (the first launches of a process include the first-call timing of the buffer roles)
+    kus[step(kname)] += sum(v) / len(v)
+res["_kernel_us"] = dict(kus)
 res["_source"] = os.path.basename(root) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
