@@ -12,8 +12,10 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpbhip.so")
-SOURCES = ["pbhip.hip", "pbhip_api.cpp"]
-HEADERS = ["pbh_config.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", "mixed_kernels.hpp", "fd4_kernels.hpp", "host_sched.hpp",
+UNITS = ["pbhip.hip", "pbhip_stream.hip", "pbhip_measure.hip"]   # each compiled twice: float32 and -DPBH_F64 (pbhip_internal.hpp)
+SOURCES = UNITS + ["pbhip_api.cpp"]
+HEADERS = ["pbh_config.hpp", "pbhip_internal.hpp", "fft_core.hpp", "kernels.hpp", "aux_kernels.hpp", "mixed_kernels.hpp", "fd4_kernels.hpp",
+           "bench_kernels.hpp", "host_sched.hpp",
            os.path.join("..", "..", "include", "pbhip.h")]
 ARCH = "gfx950"
 STAMP = LIB + ".sources"   # SHA-256 of the sources and flags the library was built from (travels with it to the GPU box)
@@ -52,13 +54,16 @@ def build(force=False, verbose=False):
         return LIB
     # -fno-slp-vectorize: v_pk_*_f32 has no rate advantage on gfx950 (tools/micro/pkrate.hip) and its even-aligned register
     # pairs inflate VGPR pressure in the fully unrolled butterflies.
-    # pbhip.hip is compiled twice: float32 (pbh32_*) and float64 (-DPBH_F64, pbh64_*); pbhip_api.cpp
-    # owns the public pbh_* symbols and dispatches on the plan's dtype.
+    # the three units are compiled twice each: float32 (pbh32_*) and float64 (-DPBH_F64, pbh64_*); pbhip_api.cpp
+    # owns the public pbh_* symbols and dispatches on the plan's dtype.  Seven hipcc processes run side by side.
     common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
     common += os.environ.get("PBH_EXTRA_FLAGS", "").split()  # e.g. -DPBH_DIAGNOSTIC for the ablation kernels
-    jobs = [("pbhip32.o", common + ["-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
-            ("pbhip64.o", common + ["-DPBH_F64", "-Rpass-analysis=kernel-resource-usage", "-c", "pbhip.hip"]),
-            ("pbhip_api.o", common + ["-x", "hip", "-c", "pbhip_api.cpp"])]
+    jobs = []
+    for unit in UNITS:
+        stem = unit[:-4].replace("pbhip", "pbhip%s", 1)   # pbhip32.o, pbhip32_stream.o, ...
+        jobs.append((stem % "32" + ".o", common + ["-Rpass-analysis=kernel-resource-usage", "-c", unit]))
+        jobs.append((stem % "64" + ".o", common + ["-DPBH_F64", "-Rpass-analysis=kernel-resource-usage", "-c", unit]))
+    jobs.append(("pbhip_api.o", common + ["-x", "hip", "-c", "pbhip_api.cpp"]))
     procs = [(obj, subprocess.Popen(cmd + ["-o", obj], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                     text=True)) for obj, cmd in jobs]
     logs = []

@@ -31,6 +31,7 @@ __host__ __device__ __forceinline__ cf make_cf(real x, real y) { return PBH_MAKE
 constexpr int kTileLog2 = PBH_TILE_LOG2;
 constexpr int kTilePoints = 1 << kTileLog2;  // complex points per workgroup tile
 constexpr int kTwTable = 1 << 14;            // stage twiddle table: W_16384^p (forward sign)
+constexpr int kMixMaxStages = 14;            // stages of a mixed-radix transform (mixed_kernels.hpp; a member of the plan structure)
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_cf(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_cf(a.x - b.x, a.y - b.y); }

@@ -22,7 +22,7 @@
 
 namespace PBH_NS {
 
-constexpr int kMixMaxStages = 14;
+// (kMixMaxStages: fft_core.hpp -- the plan structure of pbhip_internal.hpp needs it without this header)
 constexpr int kMixMaxLen = 1024;   // rows of a tile at most (64-byte pieces beyond 512 rows of complex64)
 
 struct MixParams {

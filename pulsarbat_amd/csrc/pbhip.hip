@@ -1,109 +1,16 @@
-// pbhip.hip -- host side of libpbhip.so: plans, launch sequences and the C ABI of include/pbhip.h.
-// Compiled twice (float32, and float64 with -DPBH_F64): every public name below is renamed to the
-// per-precision prefix (pbh32_* / pbh64_*); pbhip_api.cpp owns the public pbh_* symbols and dispatches
-// on the plan's dtype.
-#include "pbh_config.hpp"
-#define pbh_plan PBH_FN(plan)
-#define pbh_device_count PBH_FN(device_count)
-#define pbh_last_error PBH_FN(last_error)
-#define pbh_version PBH_FN(version)
-#define pbh_plan_create PBH_FN(plan_create)
-#define pbh_plan_destroy PBH_FN(plan_destroy)
-#define pbh_plan_set_stream PBH_FN(plan_set_stream)
-#define pbh_plan_set_variant PBH_FN(plan_set_variant)
-#define pbh_plan_info PBH_FN(plan_info)
-#define pbh_chirp_generate PBH_FN(chirp_generate)
-#define pbh_chirp_upload PBH_FN(chirp_upload)
-#define pbh_chirp_upload_as PBH_FN(chirp_upload_as)
-#define pbh_chirp_download PBH_FN(chirp_download)
-#define pbh_chirp_function PBH_FN(chirp_function)
-#define pbh_chirp_special PBH_FN(chirp_special)
-#define pbh_mix PBH_FN(mix)
-#define pbh_zero_edges PBH_FN(zero_edges)
-#define pbh_pol_basis PBH_FN(pol_basis)
-#define pbh_decimate2 PBH_FN(decimate2)
-#define pbh_incoherent PBH_FN(incoherent)
-#define pbh_incoherent_series PBH_FN(incoherent_series)
-#define pbh_transfer PBH_FN(transfer)
-#define pbh_decode PBH_FN(decode)
-#define pbh_trim PBH_FN(trim)
-#define pbh_relayout PBH_FN(relayout)
-#define pbh_dedisperse_stream_raw PBH_FN(dedisperse_stream_raw)
-#define pbh_dedisperse PBH_FN(dedisperse)
-#define pbh_dedisperse_layout PBH_FN(dedisperse_layout)
-#define pbh_dedisperse_slice PBH_FN(dedisperse_slice)
-#define pbh_dedisperse_slices PBH_FN(dedisperse_slices)
-#define pbh_dedisperse_mix PBH_FN(dedisperse_mix)
-#define pbh_place PBH_FN(place)
-#define pbh_dedisperse_detect_layout PBH_FN(dedisperse_detect_layout)
-#define pbh_dedisperse_detect PBH_FN(dedisperse_detect)
-#define pbh_dedisperse_stream PBH_FN(dedisperse_stream)
-#define pbh_stream_stats PBH_FN(stream_stats)
-#define pbh_plan_stream_detect PBH_FN(plan_stream_detect)
-#define pbh_dedisperse_istft PBH_FN(dedisperse_istft)
-#define pbh_real_to_complex PBH_FN(real_to_complex)
-#define pbh_detect PBH_FN(detect)
-#define pbh_fft_c2c PBH_FN(fft_c2c)
-#define pbh_plan_profile PBH_FN(plan_profile)
-#define pbh_copy_bench PBH_FN(copy_bench)
-#define pbh_stream_bench PBH_FN(stream_bench)
-#define pbh_plan_buffer_class PBH_FN(plan_buffer_class)
-#include "../../include/pbhip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <string>
-#include <algorithm>
-#include <vector>
+// pbhip.hip -- host side of libpbhip.so, unit 1 of 3: plans, launch sequences, chirp, and the entry points of the hot path, of the
+// next rows and of the stand-alone transforms (pbhip_internal.hpp lists the units).  Compiled twice (float32, and float64 with
+// -DPBH_F64): every public name is renamed to the per-precision prefix (pbh32_* / pbh64_*); pbhip_api.cpp owns the public pbh_*
+// symbols and dispatches on the plan's dtype.
+#include "pbhip_internal.hpp"
 
 #include "aux_kernels.hpp"
 #include "kernels.hpp"
 #include "mixed_kernels.hpp"
 #include "fd4_kernels.hpp"
-#include "host_sched.hpp"
 
-using namespace PBH_NS;
-
-// ---- environment switches ---------------------------------------------------------------------------------
-// SHIPPED (read by every build, documented in README.md "Environment"): PBH_FD4 (0: five-pass schedule only), PBH_CLASS
-// (0: no allocation-class probing), PBH_TRACE_ALLOC (allocations and placement decisions on stderr), PBH_STREAM_WINDOW_MB and
-// PBH_STREAM_EPOCH (device window of the streaming drivers), PBH_QMAX (rows of a column tile: forces the split column transform
-// at small sizes), PBH_ROW_GRID (workgroups of the persistent kernels; default one per CU), PBH_MIXED (7-smooth lengths: 0
-// padded convolution, 1 one-level plans, 2 two-level too).  Everything else is an EXPERIMENT switch of the A/B runs recorded
-// in DESIGN.md 6-6d and exists only in builds made with PBH_EXTRA_FLAGS="-DPBH_DIAGNOSTIC": a product build takes the default
-// (tests/test_abi.py counts the getenv calls of the shipped sources).
-static inline const char* diag_env(const char* name) {
-#ifdef PBH_DIAGNOSTIC
-    return getenv(name);
-#else
-    (void)name;
-    return nullptr;
-#endif
-}
-
-// ---- error plumbing ------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-#define HIPCHECK(expr)                                                                     \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(PBH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
-    } while (0)
-#define PBHCHECK(expr)              \
-    do {                            \
-        int r_ = (expr);            \
-        if (r_ != PBH_OK) return r_; \
-    } while (0)
+namespace PBH_NS {
+thread_local std::string g_err;
 
 static int ilog2(int64_t x) {
     int l = 0;
@@ -230,95 +137,8 @@ static bool rowmix_pays(int64_t n) {
     return !is_pow2(L) || (double)L / (double)n >= 2.2;
 }
 
-// ---- plan ------------------------------------------------------------------------------------------------
-constexpr size_t kCounterBytes = 4096;   // tile hand-out counters of the persistent kernels, behind the stage twiddle table
-constexpr int kCounters = (int)(kCounterBytes / sizeof(unsigned));
-struct Step {
-    const char* name;
-    std::function<int(hipStream_t)> launch;
-};
-
-struct pbh_plan {
-    int device = 0;
-    int64_t N = 0, start = 0, stop = 0;
-    int nchan = 0, npol = 0, S = 0;
-    int N1 = 1, N2 = 1;
-    int P = 1;  // N1 = P * Q: column transform split into a radix-P stage (k_radix_p) and P blocks of Q rows (k_colq)
-    int variant = PBH_VARIANT_AUTO;
-    hipStream_t stream = nullptr;
-    bool has_chirp = false;
-    int perm_w = 0;  // chirp row order: 0 natural, 8 = wave-decoupled row kernel (k_row2)
-
-    cf* work = nullptr;      // planar workspace, S * N
-    cf* work2 = nullptr;     // second planar workspace: the middle passes of the power-of-two planar pipeline ping-pong (oop_ok)
-    // Allocation "classes" (pair_class below): a pass streaming from one large allocation into another runs ~5 % faster
-    // when the two are of different class.  work2 is chosen of the class opposite to work's when it is allocated;
-    // t_same / t_diff are the probe copy's times for a same-class and a different-class pair, the cache remembers what
-    // the caller's buffers turned out to be (0 = work's class, 1 = the other, -1 = not decidable).
-    float cls_t_same = 0.f, cls_t_diff = 0.f;
-    size_t cls_len = 0;
-    struct ClsEntry { const void* ptr = nullptr; size_t bytes = 0; int cls = -1; };
-    ClsEntry cls_cache[8];
-    int cls_next = 0, cls_probes = 0;   // (at most kClassProbes probe copies per plan: a caller with ever new arrays is not probed for ever)
-    // four-pass schedule: which of the two work buffers holds the Q4 intermediate, per (input, output) pair -- decided by
-    // timing both assignments on the first call with that pair (fd4_roles)
-    struct RoleEntry { const void* in = nullptr; const void* out = nullptr; int swap = 0; };
-    RoleEntry role_cache[8];
-    int role_next = 0;
-    int role_tunes = 0, role_last = 0;   // pairs timed so far (at most kRoleTunes per plan), the last decision
-    int fd4_force = -1;   // >= 0 while fd4_roles times an assignment
-    real* det_part = nullptr;  // detect tail fused into the inverse column pass: per-tile power sums (ColpParams::det_part),
-    size_t det_bytes = 0;      // S * N / 16 floats + S * N1 * (N2 / nscrunch) for the groups with a scrunch boundary
-    cf* chirp = nullptr;     // plan order, nchan * N, pre-scaled by 1/N
-    float* chirp_phase = nullptr;  // same order, revolutions: what k_rowp reads (generated chirps only)
-    bool has_phase = false;
-    bool phase16 = false;          // ... with every 2^14-bin row in k_rowp16's order (ChirpParams::phase16)
-    cf* tw16k = nullptr;     // W_16384^p
-    double2* tw_hi = nullptr;
-    double2* tw_lo = nullptr;
-    int tw_shift = 0;
-    double* chan_freq = nullptr;
-    double* mix_ft = nullptr;   // per-series mixer frequencies of pbh_dedisperse_mix
-    // Bluestein (nsample not a power of two, or < 32): two runs of a power-of-two sub-plan
-    bool plain_fft = false;     // plan backs pbh_fft_c2c: Bluestein ring for every length, no chirp buffer
-    int64_t bsL = 0;            // ring length, power of two >= 2N-1; 0 = not a Bluestein plan
-    pbh_plan* sub = nullptr;    // (bsL, 1 chan, S "pols") plan whose chirp is FFT_L(wrapped conj b)/L
-    cf* bs_b = nullptr;         // b[n] = exp(-i pi n^2/N)
-    cf* bs_a = nullptr;         // (bsL, S) pipeline input
-    cf* bs_conv = nullptr;      // (bsL, S) pipeline output
-    // Dedispersion of such lengths is ONE power-of-two run: ifft_N(fft_N(x) H) is the circular convolution
-    // of x with h = ifft_N(H), i.e. outputs N-1 .. 2N-2 of the linear convolution of x with the N-periodic
-    // h laid out over 2N-1 taps, and that is the pipeline of a (bsL, nchan, npol) plan whose "chirp" is
-    // FFT_L of those taps and whose crop is [N-1+start, N-1+stop)  (rebuild_circular_filter)
-    pbh_plan* cfilt = nullptr;
-    cf* cf_in = nullptr;        // (bsL, S) zero-padded copy of the input
-    void* stage_in = nullptr;   // device staging for host inputs
-    void* stage_out = nullptr;  // device staging for host outputs
-    size_t stage_in_bytes = 0, stage_out_bytes = 0;
-    void* det_mid = nullptr;    // dedispersed voltages of the two-step detect (plans / scrunch factors without a fused tail)
-    size_t det_mid_bytes = 0;
-    int64_t owned_bytes = 0;
-    // 7-smooth lengths (mixed_kernels.hpp): N = N1 * N2, N2 = 2^k rows of the power-of-two engine, N1 = P * Q any 7-smooth
-    // number with P, Q <= kMixMaxLen; both column roles run k_colmix (mixP: the P-point stage, mixQ: the Q-point pass)
-    struct MixTable {
-        int L = 0, nstage = 0;
-        int radix[kMixMaxStages] = {};
-        cf* wl = nullptr;
-        unsigned short* perm = nullptr;
-    };
-    bool mixed = false;
-    MixTable mixP, mixQ;
-    // ... and, when the length has too few factors of two for the 2^k engine's rows, the rows as well (k_rowmix): mixR.perm
-    // is then the chirp's row order (position -> bin)
-    bool rowmix = false;
-    MixTable mixR;
-    double stream_stats[PBH_STREAM_NSTATS] = {};   // of the last streaming call (pbh_stream_stats)
-    int stream_detect_mode = -1, stream_detect_ns = 1;   // pbh_plan_stream_detect: the streaming calls write detected rows
-    double gen_coeff = 0, gen_inv_ndt = 0, gen_inv_ref = 0;   // parameters of the generated chirp (k_rowp16's on-the-fly phase)
-    bool chirp_lazy = false;   // the generated chirp exists as phase rows only; `chirp` is filled by materialize_chirp on demand
-};
-
-static int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
+// ---- plan: struct pbh_plan, Step, DetectTail, IoLayout are in pbhip_internal.hpp ----------------------------------------
+int dev_alloc(pbh_plan* p, void** ptr, size_t bytes) {
     hipError_t e = hipMalloc(ptr, bytes);
     if (e != hipSuccess)
         return fail(PBH_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
@@ -890,7 +710,7 @@ static int launch_reint_radix(int S, int P, const cf* work, cf* out, int64_t N, 
     return fail(PBH_ERR_UNSUPPORTED, "fused radix layout pass: unsupported series count");
 }
 
-int pbh_relayout(int device, void* hip_stream, int, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
+extern "C" int pbh_relayout(int device, void* hip_stream, int, const void* in_dev, int in_layout, int64_t in_pitch, void* out_dev,
                  int out_layout, int64_t out_pitch, int64_t nsample, int nseries) {
     if (!in_dev || !out_dev) return fail(PBH_ERR_INVALID, "NULL argument");
     if (nsample <= 0 || nseries <= 0) return fail(PBH_ERR_INVALID, "non-positive size");
@@ -916,10 +736,6 @@ int pbh_relayout(int device, void* hip_stream, int, const void* in_dev, int in_l
 }
 
 // Kernel sequence of one dedispersion: in (N,S) interleaved -> out (stop-start, S) interleaved.
-struct DetectTail {
-    real* out = nullptr;   // non-null: replace the final layout pass by detect + scrunch into `out`
-    int mode = 0, nscrunch = 1;
-};
 
 // Ping-pong schedule of the planar pipeline's middle passes (column, row, column): each pass reads one planar buffer and
 // writes the other instead of updating `work` in place.  OPT-IN (PBH_OOP=1), because it does not pay: a plain in-place
@@ -1072,7 +888,6 @@ static cf* ensure_work2(pbh_plan* p) {
 #endif
 
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
-static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode);
 
 // Detection inside the inverse column pass (k_colq<.., DET> + k_detect_reduce): for |z|^2 and Stokes I, whose sums need one
 // series at a time.  PBH_DETECT_COLQ=0 restores the separate read pass over the dedispersed voltages (k_detect_planar).
@@ -1181,18 +996,6 @@ static MixParams mix_role_b(const pbh_plan* p, const cf* ld, int64_t ldp, cf* st
 }
 
 // device layouts of the two ends (pbh_dedisperse_layout); pitches in elements, used when series-major
-struct IoLayout {
-    int in_layout = PBH_LAYOUT_SAMPLE_MAJOR, out_layout = PBH_LAYOUT_SAMPLE_MAJOR;
-    int64_t in_pitch = 0, out_pitch = 0;
-    int64_t in_valid = -1;   // sample-major input: time samples present (the rest of nsample is zero padding); -1 = all
-    const double* mix_ft = nullptr;   // sample-major input: per-series mixer frequencies (device), applied by the de-interleave pass
-    int64_t out_row_elems = 0;   // sample-major output: elements between consecutive rows (0 = compact, S): the rows are a
-                                 // channel slice of a wider (nout, nchan_total, npol) array (pbh_dedisperse_slice)
-    // the output rows may be split over several buffers (row-chunks of a destination block, each its own allocation):
-    // part i holds output rows [part_row[i], part_row[i+1]) starting at part_ptr[i]; empty = one buffer, `out`
-    std::vector<cf*> part_ptr;
-    std::vector<int64_t> part_row;
-};
 
 // the final layout pass, once per output part (IoLayout::part_ptr) or once for the whole output
 static int launch_reinterleave_parts(const cf* work, cf* out, int64_t start, int64_t stop, int S, int64_t plane, hipStream_t st,
@@ -1219,8 +1022,6 @@ static bool single_planar_ok(const pbh_plan* p) {
     return mode == 2 || (int64_t)p->S * M >= (1LL << 21);
 }
 
-static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail, IoLayout io);
-static int run_steps(std::vector<Step>& steps, hipStream_t st);
 #ifndef PBH_F64
 // Which work buffer takes the Q4 intermediate of the four-pass schedule?  The allocation classes say it for clear cases, but a
 // 1-GiB probe copy separates the classes by 3-5 % only and the caller's buffers can be of either; the passes themselves are the
@@ -1276,8 +1077,7 @@ static int fd4_roles(pbh_plan* p, const cf* in, cf* out, const DetectTail& tail,
 }
 #endif
 
-static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail = DetectTail(),
-                                     IoLayout io = IoLayout()) {
+std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tail, IoLayout io) {
     std::vector<Step> steps;
     const int S = p->S;
     if (p->bsL && p->cfilt) {
@@ -1782,7 +1582,7 @@ static std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectT
     return steps;
 }
 
-static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
+bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
     // multi-pass planar plans, and one-tile plans that run layout pass + planar rows + layout pass (many series)
     const bool planar = (p->N1 > 1 && resolved_variant(p) == PBH_VARIANT_PLANAR5) || (p->N1 == 1 && p->work && !p->bsL && single_planar_ok(p));
     if (!planar || p->nchan > 65535) return false;
@@ -1791,7 +1591,7 @@ static bool can_fuse_detect(const pbh_plan* p, int nscrunch, int mode) {
     return nscrunch == 1 && !p->bsL && reint_detect_ok(p->S, p->npol, mode, p->N);
 }
 
-static int run_steps(std::vector<Step>& steps, hipStream_t st) {
+int run_steps(std::vector<Step>& steps, hipStream_t st) {
     for (auto& s : steps) PBHCHECK(s.launch(st));
     return PBH_OK;
 }
@@ -1839,7 +1639,7 @@ Bounce* bounce_for_current_device() {
 }
 }  // namespace
 
-static hipError_t xfer_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+hipError_t xfer_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
     Bounce* b = bytes >= kBounceMin ? bounce_for_current_device() : nullptr;
     if (!b) {
         hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st);
@@ -1860,7 +1660,7 @@ static hipError_t xfer_h2d(void* dst_dev, const void* src_host, size_t bytes, hi
     return e != hipSuccess ? e : e2;
 }
 
-static hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
+hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
     Bounce* b = bytes >= kBounceMin ? bounce_for_current_device() : nullptr;
     if (!b) {
         hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st);
@@ -1886,7 +1686,7 @@ static hipError_t xfer_d2h(void* dst_host, const void* src_dev, size_t bytes, hi
 
 // Page-lock a caller's host range for asynchronous copies.  0: registered here (unregister afterwards); 1: the caller
 // had pinned it already (both ends of the range are host-registered memory); -1: it cannot be pinned.
-static int pin_host_range(void* ptr, size_t bytes) {
+int pin_host_range(void* ptr, size_t bytes) {
     if (bytes == 0) return 1;
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
     if (e == hipSuccess) return 0;
@@ -1900,13 +1700,13 @@ static int pin_host_range(void* ptr, size_t bytes) {
 
 // Layout conversion of a device (nsample, nseries) array (DeviceArray.to_series_major / contiguous): one transposing
 // pass with the pipeline's own layout kernels.
-int pbh_relayout(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_dev, int in_layout, int64_t in_pitch,
+extern "C" int pbh_relayout(int device, void* hip_stream, int /*dtype: this build's*/, const void* in_dev, int in_layout, int64_t in_pitch,
                  void* out_dev, int out_layout, int64_t out_pitch, int64_t nsample, int nseries);
 
 // Plain copy between caller (host) memory and device memory through the bounce buffers above; what
 // pulsarbat_amd.DeviceArray uses for from_host() / get() so that no pageable caller memory is ever
 // handed to the runtime by this package.  direction: 0 = host -> device, 1 = device -> host.  Blocking.
-int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_t bytes, int direction) {
+extern "C" int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_t bytes, int direction) {
     if (bytes == 0) return PBH_OK;
     if (!dst || !src) return fail(PBH_ERR_INVALID, "NULL argument");
     if (direction != 0 && direction != 1) return fail(PBH_ERR_INVALID, "bad direction");
@@ -1917,18 +1717,17 @@ int pbh_transfer(int device, void* hip_stream, void* dst, const void* src, size_
 }
 
 // Reader-side decode (include/pbhip.h): every byte the kernel will touch is bounds-checked here first.
-typedef pbh_host::Span DecodeSpan;   // {b0, b1: first / last block touched; off, len: bytes [off, off + len) of the raw buffer read}
 
 // (the arithmetic lives in host_sched.hpp, where the CPU box runs it under the sanitizers)
-static int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan, int npol, size_t raw_bytes,
-                       DecodeSpan* sp) {
+int decode_span(const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan, int npol, size_t raw_bytes,
+                DecodeSpan* sp) {
     const char* why = "bad argument";
     const int rc = pbh_host::decode_span(L, first, nsample, nchan, npol, raw_bytes, sp, &why);
     return rc == PBH_OK ? rc : fail(rc, why);
 }
 
 // draw: device copy of the raw stream from byte `skip` on (only offsets inside the checked span are formed)
-static int decode_launch(const unsigned char* draw, int64_t skip, const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan,
+int decode_launch(const unsigned char* draw, int64_t skip, const pbh_raw_layout_t* L, int64_t first, int64_t nsample, int nchan,
                          int npol, const unsigned char* dconj, float scale, void* out_dev, int out_layout,
                          int64_t out_pitch, hipStream_t st) {
     DecodeParams q;
@@ -1983,7 +1782,7 @@ static int decode_launch(const unsigned char* draw, int64_t skip, const pbh_raw_
     return PBH_OK;
 }
 
-int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* L,
+extern "C" int pbh_decode(int device, void* hip_stream, const void* raw, size_t raw_bytes, int raw_loc, const pbh_raw_layout_t* L,
                int64_t first, int64_t nsample, int nchan, int npol, const unsigned char* conj_mask, float scale,
                void* out_dev, int out_layout, int64_t out_pitch) {
     if (!L || (!raw && raw_bytes) || (!out_dev && nsample)) return fail(PBH_ERR_INVALID, "NULL argument");
@@ -3264,7 +3063,7 @@ int pbh_dedisperse_mix(pbh_plan* p, const void* in_dev, void* out_dev, const dou
     return run_steps(steps, p->stream);
 }
 
-static int detect_out_elems(int mode, int npol) {
+extern "C++" int detect_out_elems(int mode, int npol) {
     switch (mode) {
         case PBH_DETECT_INTENSITY: return npol;
         case PBH_DETECT_STOKES_I: return 1;
@@ -3891,461 +3690,5 @@ int PBH_FN(stft)(int device, void* hip_stream, int /*dtype*/, const void* in, vo
     return PBH_OK;
 }
 
-// ---- streaming overlap-save (BASELINE configs[3]) ---------------------------------------------------------------------
-// A long host-resident block is dedispersed in chunks of plan->N samples that overlap by N - hop,
-// hop = stop - start: chunk k covers input rows [k*hop, k*hop + N) and yields output rows
-// [k*hop, (k+1)*hop) -- exactly `concatenate([coherent_dedispersion(z[k*hop : k*hop+N]) for k])` of the
-// reference (each chunk is one reference call; its crop is the valid region of an overlap-save step:
-// dedispersion.py:127-133, transforms.py:59-148).
-//
-// Every input row crosses PCIe ONCE.  The stream's samples exist once on the host (transforms.py:101-110; readers are
-// offset-addressed, readers/_base.py:298-333) and the N - hop rows two consecutive chunks share stay in HBM: the device
-// holds a WINDOW of N + (B-1)*hop consecutive rows; chunk k of an epoch of B chunks reads rows [j*hop, j*hop + N) of it
-// (j = k mod B) and only the hop rows it adds are uploaded.  Two windows alternate between epochs: the first chunk of an
-// epoch gets the N - hop rows it shares with its predecessor by one device-to-device copy out of the other window's tail
-// (on the compute stream), so uploads never wait for kernels except for the window of two epochs ago.  H2D, kernels and D2H
-// run on three streams chained by events.  Host memory is page-locked for the duration of the call (hipHostRegister); a
-// range that cannot be page-locked and is not pinned already is an error -- pageable memory is never handed to
-// hipMemcpyAsync (see "host <-> device transfers" above).
-namespace {
-struct StreamRig {
-    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    hipEvent_t ev_epoch[2] = {nullptr, nullptr};   // window w has been read for the last time (chunks and the slide out of it)
-    hipEvent_t t[6] = {};                          // timing: whole call, H2D stream, D2H stream (first / last)
-    std::vector<hipEvent_t> kev;                   // timing: around every chunk's kernels
-    void* reg[2] = {nullptr, nullptr};             // host ranges registered by this call
-    int rc = PBH_OK;
-    const char* who;
-
-    explicit StreamRig(const char* name) : who(name) {}
-    bool ok(hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string(who) + ": " + what + ": " + hipGetErrorString(e));
-        return e == hipSuccess;
-    }
-    void pin(int slot, void* ptr, size_t bytes) {
-        if (rc != PBH_OK) return;
-        const int r = pin_host_range(ptr, bytes);
-        if (r == 0) reg[slot] = ptr;
-        if (r < 0)
-            rc = fail(PBH_ERR_HIP, std::string(who) + ": the host buffers cannot be page-locked (hipHostRegister failed); "
-                                   "pageable memory is never handed to asynchronous copies");
-    }
-    void create(int64_t nchunk) {
-        if (rc != PBH_OK) return;
-        ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate");
-        ok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking), "hipStreamCreate");
-        ok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
-        for (int b = 0; b < 2; ++b) {
-            ok(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming), "hipEventCreate");
-            ok(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming), "hipEventCreate");
-            ok(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming), "hipEventCreate");
-            ok(hipEventCreateWithFlags(&ev_epoch[b], hipEventDisableTiming), "hipEventCreate");
-        }
-        for (auto& e : t) ok(hipEventCreate(&e), "hipEventCreate");
-        kev.assign((size_t)(2 * nchunk), nullptr);
-        for (auto& e : kev) ok(hipEventCreate(&e), "hipEventCreate");
-    }
-    // after the last chunk has been enqueued: drain, read the clocks (stats: see pbh_stream_stats in pbhip.h)
-    void finish(double* stats, float* ms_total) {
-        ok(hipStreamSynchronize(s_in), "hipStreamSynchronize");
-        ok(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");
-        ok(hipEventRecord(t[1], s_out), "hipEventRecord");
-        ok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
-        if (rc != PBH_OK) return;
-        float ms = 0.f;
-        if (ok(hipEventElapsedTime(&ms, t[0], t[1]), "hipEventElapsedTime")) stats[5] = ms;
-        if (ms_total) *ms_total = ms;
-        if (ok(hipEventElapsedTime(&ms, t[2], t[3]), "hipEventElapsedTime")) stats[2] = ms;
-        if (ok(hipEventElapsedTime(&ms, t[4], t[5]), "hipEventElapsedTime")) stats[3] = ms;
-        double kms = 0.0;
-        for (size_t k = 0; k + 1 < kev.size() && rc == PBH_OK; k += 2)
-            if (ok(hipEventElapsedTime(&ms, kev[k], kev[k + 1]), "hipEventElapsedTime")) kms += ms;
-        stats[4] = kms;
-    }
-    ~StreamRig() {
-        for (void* r : reg)
-            if (r) (void)hipHostUnregister(r);
-        for (int b = 0; b < 2; ++b) {
-            if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
-            if (ev_cmp[b]) (void)hipEventDestroy(ev_cmp[b]);
-            if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
-            if (ev_epoch[b]) (void)hipEventDestroy(ev_epoch[b]);
-        }
-        for (auto e : t)
-            if (e) (void)hipEventDestroy(e);
-        for (auto e : kev)
-            if (e) (void)hipEventDestroy(e);
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_cmp) (void)hipStreamDestroy(s_cmp);
-        if (s_out) (void)hipStreamDestroy(s_out);
-    }
-};
-
-// chunks per epoch: as many as keep a window within `PBH_STREAM_WINDOW_MB` (default 2048 MiB), at most 64, or exactly
-// `PBH_STREAM_EPOCH` (both read per call so that tests can force many short epochs); `step_bytes` = what one more chunk
-// adds to the window
-static size_t stream_window_cap() {
-    const char* e = getenv("PBH_STREAM_WINDOW_MB");
-    return (size_t)(e && atoll(e) > 0 ? atoll(e) : 2048) << 20;
-}
-static int64_t stream_epoch_max() {
-    const char* e = getenv("PBH_STREAM_EPOCH");
-    const int64_t v = e ? atoll(e) : 0;
-    return v >= 1 && v <= 64 ? v : 0;   // 0: not forced
-}
-}  // namespace
-
-// Detected output of the streaming calls (pbh_plan_stream_detect): every chunk ends in the fused detect tail and what goes
-// back to the host is float32 (hop / nscrunch, nchan[, npol | 4]) rows -- a filterbank stream; the chunks' valid regions
-// must be whole scrunch blocks (hop % nscrunch == 0) for the concatenation to be the scrunched stream.
-int pbh_plan_stream_detect(pbh_plan* p, int mode, int nscrunch) {
-    if (!p) return fail(PBH_ERR_INVALID, "plan is NULL");
-    if (mode < 0) {
-        p->stream_detect_mode = -1;
-        p->stream_detect_ns = 1;
-        return PBH_OK;
-    }
-    if (nscrunch <= 0) return fail(PBH_ERR_INVALID, "nscrunch must be positive");
-    if (!detect_out_elems(mode, p->npol)) return fail(PBH_ERR_INVALID, "bad detect mode");
-    if (mode != PBH_DETECT_INTENSITY && p->npol != 2) return fail(PBH_ERR_INVALID, "Stokes modes need npol == 2");
-    if ((p->stop - p->start) % nscrunch != 0)
-        return fail(PBH_ERR_INVALID, "the plan's valid region (crop_stop - crop_start) must be a multiple of nscrunch");
-    if (!can_fuse_detect(p, nscrunch, mode))
-        return fail(PBH_ERR_UNSUPPORTED, "no fused detect tail for this plan and nscrunch (multi-pass plans; nscrunch % 64 == 0, or 1)");
-    p->stream_detect_mode = mode;
-    p->stream_detect_ns = nscrunch;
-    return PBH_OK;
-}
-// bytes one chunk of a streaming call leaves, and the tail that makes them
-static size_t stream_out_bytes(const pbh_plan* p) {
-    const int64_t hop = p->stop - p->start;
-    if (p->stream_detect_mode < 0) return sizeof(cf) * (size_t)p->S * (size_t)hop;
-    return sizeof(real) * (size_t)(hop / p->stream_detect_ns) * (size_t)p->nchan * (size_t)detect_out_elems(p->stream_detect_mode, p->npol);
-}
-static DetectTail stream_tail(const pbh_plan* p, void* dout) {
-    DetectTail t;
-    if (p->stream_detect_mode >= 0) {
-        t.out = (real*)dout;
-        t.mode = p->stream_detect_mode;
-        t.nscrunch = p->stream_detect_ns;
-    }
-    return t;
-}
-
-int pbh_stream_stats(const pbh_plan* p, double* out, int n) {
-    if (!p || !out || n < 0) return fail(PBH_ERR_INVALID, "NULL argument");
-    for (int i = 0; i < n; ++i) out[i] = i < PBH_STREAM_NSTATS ? p->stream_stats[i] : 0.0;
-    return PBH_OK;
-}
-
-int pbh_dedisperse_stream(pbh_plan* p, const void* host_in, int64_t total_nsample, void* host_out,
-                          int64_t* nchunk_out, float* ms_total) {
-    if (!p || !host_in || !host_out) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
-    const int64_t N = p->N, hop = p->stop - p->start;
-    if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
-    if (total_nsample < N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
-    HIPCHECK(hipSetDevice(p->device));
-    const size_t row = sizeof(cf) * (size_t)p->S;
-    // the schedule (epochs, windows, what every chunk uploads and takes over): host_sched.hpp
-    pbh_host::RowStream sched;
-    if (!pbh_host::row_stream(N, hop, total_nsample, row, stream_window_cap(), stream_epoch_max(), &sched))
-        return fail(PBH_ERR_INVALID, "bad stream geometry");
-    const int64_t nchunk = sched.nchunk;
-    const size_t out_bytes = stream_out_bytes(p);
-    const size_t host_in_bytes = row * (size_t)total_nsample, host_out_bytes = out_bytes * (size_t)nchunk;
-    const size_t win_bytes = sched.win_bytes;
-    const int nwin = sched.nwin;
-
-    void* dwin[2] = {nullptr, nullptr};
-    void* dout[2] = {nullptr, nullptr};
-    StreamRig rig("pbh_dedisperse_stream");
-    int& rc = rig.rc;
-    double* stats = p->stream_stats;
-    for (int i = 0; i < PBH_STREAM_NSTATS; ++i) stats[i] = 0.0;
-    for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
-        if (b < nwin && (rc = dev_alloc(nullptr, &dwin[b], win_bytes)) != PBH_OK) break;
-        rc = dev_alloc(nullptr, &dout[b], out_bytes);
-    }
-    rig.pin(0, const_cast<void*>(host_in), host_in_bytes);
-    rig.pin(1, host_out, host_out_bytes);
-    rig.create(nchunk);
-    if (rc == PBH_OK) {
-        // the plan's own stream may hold pending work (chirp generation): order after it
-        rig.ok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
-        rig.ok(hipEventRecord(rig.t[0], rig.s_in), "hipEventRecord");
-        rig.ok(hipEventRecord(rig.t[2], rig.s_in), "hipEventRecord");
-        rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.t[0], 0), "hipStreamWaitEvent");
-        for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const pbh_host::RowChunk c = pbh_host::row_chunk(sched, k);
-            const int64_t e = c.epoch, j = c.j;
-            const int w = c.win, b = (int)(k & 1);
-            char* win = (char*)dwin[w];
-            char* dst = (char*)host_out + (size_t)k * out_bytes;
-            // upload the rows this chunk adds: all N for the first chunk, afterwards rows [(k-1)*hop + N, k*hop + N)
-            if (j == 0 && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
-            rig.ok(hipMemcpyAsync(win + c.up_dst, (const char*)host_in + c.up_src, c.up_bytes, hipMemcpyHostToDevice, rig.s_in),
-                   "hipMemcpyAsync H2D");
-            stats[0] += (double)c.up_bytes;
-            rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
-            rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
-            if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
-            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
-            if (c.handover) {   // a new epoch: the shared rows come from the tail of the other window, which is then free
-                if (c.ho_bytes > 0)
-                    rig.ok(hipMemcpyAsync(win, (const char*)dwin[w ^ 1] + c.ho_src, c.ho_bytes, hipMemcpyDeviceToDevice, rig.s_cmp),
-                           "hipMemcpyAsync D2D");
-                stats[7] += (double)c.ho_bytes;
-                rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
-            }
-            if (rc == PBH_OK) {
-                const DetectTail tail = stream_tail(p, dout[b]);
-                auto steps = build_steps(p, (const cf*)(win + c.win_off), tail.out ? nullptr : (cf*)dout[b], tail);
-                rc = run_steps(steps, rig.s_cmp);
-            }
-            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
-            rig.ok(hipEventRecord(rig.ev_cmp[b], rig.s_cmp), "hipEventRecord");
-            rig.ok(hipStreamWaitEvent(rig.s_out, rig.ev_cmp[b], 0), "hipStreamWaitEvent");
-            if (k == 0) rig.ok(hipEventRecord(rig.t[4], rig.s_out), "hipEventRecord");
-            rig.ok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, rig.s_out), "hipMemcpyAsync D2H");
-            stats[1] += (double)out_bytes;
-            rig.ok(hipEventRecord(rig.ev_out[b], rig.s_out), "hipEventRecord");
-        }
-        rig.ok(hipEventRecord(rig.t[3], rig.s_in), "hipEventRecord");
-        rig.ok(hipEventRecord(rig.t[5], rig.s_out), "hipEventRecord");
-        rig.finish(stats, ms_total);
-        stats[6] = (double)nchunk;
-    }
-    for (int b = 0; b < 2; ++b) {
-        if (dwin[b]) (void)hipFree(dwin[b]);
-        if (dout[b]) (void)hipFree(dout[b]);
-    }
-    if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
-    return rc;
-}
-
-// The same overlap-save stream fed with RAW payload bytes (reader-side decode in front): the bytes of the blocks that hold
-// the stream's samples cross PCIe once (2 bytes per 8-bit complex sample instead of 8) into the same two-window scheme, now
-// over FILE BYTES: an epoch's window holds the bytes from the (16-byte aligned) start of its first chunk's span to the end of
-// its last chunk's span, a chunk uploads only the bytes beyond its predecessor's span and a new epoch takes the bytes it
-// shares with the previous chunk from the other window.  k_decode writes each chunk series-major on the device, and the
-// chunk runs the pipeline without its de-interleave pass.
-int pbh_dedisperse_stream_raw(pbh_plan* p, const void* host_raw, size_t raw_bytes, const pbh_raw_layout_t* L,
-                              int64_t first, int64_t total_nsample, const unsigned char* conj_mask, float scale, void* host_out,
-                              int64_t* nchunk_out, float* ms_total) {
-    if (!p || !host_raw || !host_out || !L) return fail(PBH_ERR_INVALID, "NULL argument");
-#ifdef PBH_F64
-    return fail(PBH_ERR_UNSUPPORTED, "raw streaming decodes to complex64");
-#else
-    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp: call pbh_chirp_generate or pbh_chirp_upload first");
-    if (L->ncomp != 2) return fail(PBH_ERR_INVALID, "raw streaming needs complex samples (ncomp = 2)");
-    if (first < 0) return fail(PBH_ERR_INVALID, "first must be non-negative");
-    const int64_t hop = p->stop - p->start;
-    if (hop <= 0) return fail(PBH_ERR_INVALID, "plan has an empty valid region (stop <= start)");
-    if (total_nsample < p->N) return fail(PBH_ERR_INVALID, "total_nsample is shorter than one chunk");
-    const int64_t nchunk = (total_nsample - p->N) / hop + 1;
-    // spans of all chunks up front: bounds checks, then the epochs and the size of the device windows (host_sched.hpp)
-    pbh_host::SpanStream sched;
-    {
-        std::vector<DecodeSpan> spans((size_t)nchunk);
-        for (int64_t k = 0; k < nchunk; ++k)
-            PBHCHECK(decode_span(L, first + k * hop, p->N, p->nchan, p->npol, raw_bytes, &spans[(size_t)k]));
-        pbh_host::span_stream(std::move(spans), stream_epoch_max() ? stream_epoch_max() : 64,
-                              stream_epoch_max() ? SIZE_MAX : stream_window_cap(), &sched);
-    }
-    const size_t win_bytes = sched.win_bytes;
-    HIPCHECK(hipSetDevice(p->device));
-    const bool sm = !(p->bsL || p->mixed || p->N1 == 1 || p->N1 / p->P > kTilePoints || p->N2 % (kTilePoints / (p->N1 / p->P)) != 0 ||
-                      p->N >= (1LL << 31)) && p->S > 1;
-    const size_t row = sizeof(cf) * (size_t)p->S;
-    const size_t out_bytes = stream_out_bytes(p), host_out_bytes = out_bytes * (size_t)nchunk;
-    const int nwin = sched.nwin;
-
-    void* dwin[2] = {nullptr, nullptr};
-    void* dout[2] = {nullptr, nullptr};
-    void *dec = nullptr, *dconj = nullptr;
-    StreamRig rig("pbh_dedisperse_stream_raw");
-    int& rc = rig.rc;
-    double* stats = p->stream_stats;
-    for (int i = 0; i < PBH_STREAM_NSTATS; ++i) stats[i] = 0.0;
-    for (int b = 0; b < 2 && rc == PBH_OK; ++b) {
-        if (b < nwin && (rc = dev_alloc(nullptr, &dwin[b], win_bytes + 16)) != PBH_OK) break;
-        rc = dev_alloc(nullptr, &dout[b], out_bytes);
-    }
-    if (rc == PBH_OK) rc = dev_alloc(nullptr, &dec, row * (size_t)p->N);
-    bool any_conj = false;
-    if (conj_mask)
-        for (int i = 0; i < p->S; ++i) any_conj |= conj_mask[i] != 0;
-    if (rc == PBH_OK && any_conj) {
-        rc = dev_alloc(nullptr, &dconj, (size_t)p->S);
-        if (rc == PBH_OK) rig.ok(xfer_h2d(dconj, conj_mask, (size_t)p->S, p->stream), "mask copy");
-    }
-    rig.pin(0, const_cast<void*>(host_raw), raw_bytes);
-    rig.pin(1, host_out, host_out_bytes);
-    rig.create(nchunk);
-    if (rc == PBH_OK) {
-        rig.ok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
-        rig.ok(hipEventRecord(rig.t[0], rig.s_in), "hipEventRecord");
-        rig.ok(hipEventRecord(rig.t[2], rig.s_in), "hipEventRecord");
-        rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.t[0], 0), "hipStreamWaitEvent");
-        IoLayout io;
-        if (sm) {
-            io.in_layout = PBH_LAYOUT_SERIES_MAJOR;
-            io.in_pitch = p->N;
-        }
-        for (int64_t k = 0; k < nchunk && rc == PBH_OK; ++k) {
-            const pbh_host::SpanChunk c = pbh_host::span_chunk(sched, k);
-            const int e = c.epoch;
-            const bool head = c.head;                           // first chunk of its epoch
-            const int w = c.win, b = (int)(k & 1);
-            unsigned char* win = (unsigned char*)dwin[w];
-            char* dst = (char*)host_out + (size_t)k * out_bytes;
-            // file bytes [up_lo, up_hi) are new to the device; [base, up_lo) of a new epoch come out of the other window
-            if (head && e >= 2) rig.ok(hipStreamWaitEvent(rig.s_in, rig.ev_epoch[w], 0), "hipStreamWaitEvent");
-            if (c.up_hi > c.up_lo) {
-                rig.ok(hipMemcpyAsync(win + (c.up_lo - c.base), (const char*)host_raw + c.up_lo, c.up_hi - c.up_lo, hipMemcpyHostToDevice, rig.s_in),
-                       "hipMemcpyAsync H2D");
-                stats[0] += (double)(c.up_hi - c.up_lo);
-            }
-            rig.ok(hipEventRecord(rig.ev_in[b], rig.s_in), "hipEventRecord");
-            rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_in[b], 0), "hipStreamWaitEvent");
-            if (k >= 2) rig.ok(hipStreamWaitEvent(rig.s_cmp, rig.ev_out[b], 0), "hipStreamWaitEvent");  // out[b] downloaded
-            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k)], rig.s_cmp), "hipEventRecord");
-            if (head && k > 0) {
-                if (c.handover) {
-                    rig.ok(hipMemcpyAsync(win, (const unsigned char*)dwin[w ^ 1] + c.ho_src, c.ho_bytes, hipMemcpyDeviceToDevice, rig.s_cmp),
-                           "hipMemcpyAsync D2D");
-                    stats[7] += (double)c.ho_bytes;
-                }
-                rig.ok(hipEventRecord(rig.ev_epoch[w ^ 1], rig.s_cmp), "hipEventRecord");
-            }
-            if (rc == PBH_OK)
-                rc = decode_launch(win, (int64_t)c.base, L, first + k * hop, p->N, p->nchan, p->npol, (const unsigned char*)dconj, scale, dec,
-                                   sm ? PBH_LAYOUT_SERIES_MAJOR : PBH_LAYOUT_SAMPLE_MAJOR, p->N, rig.s_cmp);
-            if (rc == PBH_OK) {
-                const DetectTail tail = stream_tail(p, dout[b]);
-                auto steps = build_steps(p, (const cf*)dec, tail.out ? nullptr : (cf*)dout[b], tail, io);
-                rc = run_steps(steps, rig.s_cmp);
-            }
-            rig.ok(hipEventRecord(rig.kev[(size_t)(2 * k + 1)], rig.s_cmp), "hipEventRecord");
-            rig.ok(hipEventRecord(rig.ev_cmp[b], rig.s_cmp), "hipEventRecord");
-            rig.ok(hipStreamWaitEvent(rig.s_out, rig.ev_cmp[b], 0), "hipStreamWaitEvent");
-            if (k == 0) rig.ok(hipEventRecord(rig.t[4], rig.s_out), "hipEventRecord");
-            rig.ok(hipMemcpyAsync(dst, dout[b], out_bytes, hipMemcpyDeviceToHost, rig.s_out), "hipMemcpyAsync D2H");
-            stats[1] += (double)out_bytes;
-            rig.ok(hipEventRecord(rig.ev_out[b], rig.s_out), "hipEventRecord");
-        }
-        rig.ok(hipEventRecord(rig.t[3], rig.s_in), "hipEventRecord");
-        rig.ok(hipEventRecord(rig.t[5], rig.s_out), "hipEventRecord");
-        rig.finish(stats, ms_total);
-        stats[6] = (double)nchunk;
-    }
-    for (int b = 0; b < 2; ++b) {
-        if (dwin[b]) (void)hipFree(dwin[b]);
-        if (dout[b]) (void)hipFree(dout[b]);
-    }
-    if (dec) (void)hipFree(dec);
-    if (dconj) (void)hipFree(dconj);
-    if (rc == PBH_OK && nchunk_out) *nchunk_out = nchunk;
-    return rc;
-#endif
-}
-
-// ---- measurement ----------------------------------------------------------------------------------------------------
-int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, float* ms_per_kernel, int* nkernel,
-                     const char** names) {
-    if (!p || !in_dev || !out_dev || !ms_per_kernel || !nkernel) return fail(PBH_ERR_INVALID, "NULL argument");
-    if (!p->has_chirp) return fail(PBH_ERR_STATE, "no chirp");
-    if (iters <= 0) return fail(PBH_ERR_INVALID, "iters must be positive");
-    HIPCHECK(hipSetDevice(p->device));
-    auto steps = build_steps(p, (const cf*)in_dev, (cf*)out_dev);
-    const int nk = (int)steps.size();
-    // steps that share a name (the depth-first schedule launches each middle pass once per series) report as one entry
-    std::vector<const char*> uniq;
-    std::vector<int> slot(nk);
-    for (int k = 0; k < nk; ++k) {
-        int j = 0;
-        while (j < (int)uniq.size() && strcmp(uniq[j], steps[k].name) != 0) ++j;
-        if (j == (int)uniq.size()) uniq.push_back(steps[k].name);
-        slot[k] = j;
-    }
-    if ((int)uniq.size() > PBH_MAX_KERNELS) return fail(PBH_ERR_INVALID, "too many kernels");
-    std::vector<hipEvent_t> ev(nk + 1);
-    for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
-    std::vector<double> acc(nk, 0.0);
-    int rc = PBH_OK;
-    // every event call is checked: these durations are what bench.py's `roofline` is computed from
-    auto evok = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == PBH_OK) rc = fail(PBH_ERR_HIP, std::string("profile: ") + what + ": " + hipGetErrorString(e));
-        return e == hipSuccess;
-    };
-    for (int it = 0; it < iters && rc == PBH_OK; ++it) {
-        evok(hipEventRecord(ev[0], p->stream), "hipEventRecord");
-        for (int k = 0; k < nk && rc == PBH_OK; ++k) {
-            rc = steps[k].launch(p->stream);
-            if (rc == PBH_OK) evok(hipEventRecord(ev[k + 1], p->stream), "hipEventRecord");
-        }
-        evok(hipStreamSynchronize(p->stream), "hipStreamSynchronize");
-        for (int k = 0; k < nk && rc == PBH_OK; ++k) {
-            float ms = 0.f;
-            if (evok(hipEventElapsedTime(&ms, ev[k], ev[k + 1]), "hipEventElapsedTime")) acc[k] += ms;
-        }
-    }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    PBHCHECK(rc);
-    for (int j = 0; j < (int)uniq.size(); ++j) {
-        ms_per_kernel[j] = 0.f;
-        if (names) names[j] = uniq[j];
-    }
-    for (int k = 0; k < nk; ++k) ms_per_kernel[slot[k]] += (float)(acc[k] / iters);
-    *nkernel = (int)uniq.size();
-    return PBH_OK;
-}
-
-#ifndef PBH_F64
-// mode 0: copy a -> b (two buffers of `bytes`); mode 1: read-modify-write of ONE buffer in place (what the three middle
-// passes do to the planar work buffer).  Mean milliseconds per launch over `iters` launches, HIP events on the null stream.
-int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_mean) {
-    if (!ms_mean || bytes < 16 || iters <= 0 || mode < 0 || mode > 1) return fail(PBH_ERR_INVALID, "bad argument");
-    HIPCHECK(hipSetDevice(device));
-    void *a = nullptr, *b = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = dev_alloc(nullptr, &a, (size_t)bytes);
-    if (rc == PBH_OK && mode == 0) rc = dev_alloc(nullptr, &b, (size_t)bytes);
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return x == hipSuccess; };
-    float ms = 0.f;
-    if (rc == PBH_OK) {
-        const int64_t n = bytes / 16;
-        const unsigned grid = (unsigned)((n + 1023) / 1024);
-        auto launch = [&] {
-            if (mode == 0) hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
-            else hipLaunchKernelGGL(k_copy<true>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)a, n);
-        };
-        ok(hipMemset(a, 0, (size_t)bytes));
-        ok(hipEventCreate(&e0));
-        ok(hipEventCreate(&e1));
-        launch();
-        launch();
-        ok(hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i) launch();
-        ok(hipGetLastError());
-        ok(hipEventRecord(e1, 0));
-        ok(hipEventSynchronize(e1));
-        if (e == hipSuccess) ok(hipEventElapsedTime(&ms, e0, e1));
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (rc != PBH_OK) return rc;
-    if (e != hipSuccess) return fail(PBH_ERR_HIP, std::string("stream bench: ") + hipGetErrorString(e));
-    *ms_mean = ms / iters;
-    return PBH_OK;
-}
-int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean) { return pbh_stream_bench(device, bytes, iters, 0, ms_mean); }
-
-#endif  // !PBH_F64
-
 }  // extern "C"
+}  // namespace PBH_NS
