@@ -1004,9 +1004,12 @@ __global__ __launch_bounds__(256) void k_detect_planar(const cf* __restrict__ wo
 // after its last one (what det_part holds for a group with a boundary).  Consecutive threads follow the partial sums'
 // row order (row = x / R + MR (x % R)): coalesced reads.
 //   mode 0: out[o][chan][pol];  mode 1 (Stokes I): out[o][chan], polarisations added.
+// Round 4: the group width is a parameter (gw = 16: one float per series; gw = 8, ncomp = 4: the pol-pair form of the column
+// pass, planes |a|^2, |b|^2, Re conj(a) b, Im conj(a) b per channel) and the four-parameter modes are assembled here:
+//   mode 0: out[o][chan][pol];  mode 1 (Stokes I): out[o][chan];  mode 2 / 3 (linear / circular, core.py:930-966): out[o][chan][4].
 __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ part, const real* __restrict__ side,
                                                        real* __restrict__ out, int N2, int M, int R, int ns, int64_t start,
-                                                       int64_t nout, int nchan, int npol, int mode, int parts) {
+                                                       int64_t nout, int nchan, int npol, int mode, int parts, int gw, int ncomp) {
     // 256 / parts rows x `parts` (1, 4 or 16) pieces of an output's run of groups per workgroup (the pieces meet in LDS):
     // short runs (small scrunch factors) want many rows per workgroup, long ones many pieces
     __shared__ real sh[256];
@@ -1016,20 +1019,20 @@ __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ 
     const int kk = blockIdx.y, chan = blockIdx.z;
     const int MR = M / R;
     const int r0 = x / R + MR * (x % R);
-    const int bmod = (int)(start % ns), bcol = bmod & 15;
+    const int bmod = (int)(start % ns), bcol = bmod & (gw - 1);
     const int64_t t0 = (int64_t)r0 * N2 + (int64_t)kk * ns + bmod;
     const int64_t o = t0 >= start ? (t0 - start) / ns : -1;
     const bool live = x < M && o >= 0 && o < nout;
-    const int ngrp = N2 / 16, nb = N2 / ns, nj = ns / 16 + (bcol != 0);
+    const int ngrp = N2 / gw, nb = N2 / ns, nj = ns / gw + (bcol != 0);
     // groups g0 .. of row r0, then (when the run crosses the end of the row) groups 0 .. of row r0 + 1; the first one
     // comes from `side` when the boundary lies inside it
-    const int g0 = (kk * ns + bmod - bcol) / 16;
+    const int g0 = (kk * ns + bmod - bcol) / gw;
     const int n0 = min(nj, ngrp - g0);
     const int xn = ((r0 + 1) % MR) * R + (r0 + 1) / MR;
     const int per = (nj + parts - 1) / parts, ja = max(1, qu * per), jb = min(nj, (qu + 1) * per);
-    real tot = 0;
-    for (int pp = 0; pp < npol; ++pp) {
-        const int s = chan * npol + pp;
+    real tot = 0, comp4[4] = {0, 0, 0, 0};
+    for (int pp = 0; pp < ncomp; ++pp) {
+        const int s = chan * ncomp + pp;
         const real* ps = part + (int64_t)s * ngrp * M;
         real a[4] = {0, 0, 0, 0};
         if (live) {
@@ -1054,9 +1057,18 @@ __global__ __launch_bounds__(256) void k_detect_reduce(const real* __restrict__ 
         if (qu == 0 && live) {
             if (mode == 0) out[(o * nchan + chan) * npol + pp] = acc;
             tot += acc;
+            comp4[pp & 3] = acc;
         }
     }
-    if (qu == 0 && live && mode != 0) out[o * nchan + chan] = tot;
+    if (qu == 0 && live && mode == 1) out[o * nchan + chan] = tot;
+    if (qu == 0 && live && mode >= 2) {   // planes: |a|^2, |b|^2, Re conj(a) b, Im conj(a) b
+        real* o4 = out + (o * nchan + chan) * 4;
+        const real i = comp4[0] + comp4[1], d = comp4[0] - comp4[1], re2 = 2 * comp4[2], im2 = 2 * comp4[3];
+        o4[0] = i;
+        o4[1] = mode == 2 ? d : re2;
+        o4[2] = mode == 2 ? re2 : im2;
+        o4[3] = mode == 2 ? im2 : d;
+    }
 }
 
 // ---- Bluestein (arbitrary nsample) ---------------------------------------------------------------------------

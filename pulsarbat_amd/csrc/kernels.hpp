@@ -214,6 +214,14 @@ __device__ __forceinline__ float2 treduce16x32(const float* a, int f) {
     treduce_step<2, 0xB1>(d, e, (f & 1) != 0);
     return make_float2(e[0], e[1]);
 }
+// the same over the 8 lanes of HALF a DPP row (partners f^7, f^2, f^1): lane f & 7 ends with the totals of values 4f .. 4f + 3
+__device__ __forceinline__ float4 treduce8x32(const float* a, int f) {
+    float c[16], d[8], e[4];
+    treduce_step<16, 0x141>(a, c, (f & 4) != 0);
+    treduce_step<8, 0x4E>(c, d, (f & 2) != 0);
+    treduce_step<4, 0xB1>(d, e, (f & 1) != 0);
+    return make_float4(e[0], e[1], e[2], e[3]);
+}
 #endif
 
 // ---- persistent column pass with deferred, interleaved stores --------------------------------------
@@ -225,10 +233,16 @@ __device__ __forceinline__ float2 treduce16x32(const float* a, int f) {
 // is two tiles of registers (the one being transformed, and the out/in slots).  Out-of-range
 // descriptors (0 bytes) turn the first iteration's stores and the last iterations' loads into
 // no-ops without branches.
-template <int M, int OP, int R, bool DET = false>
+// DET: 0 = voltages stored; 1 = |z|^2 summed over every 16 columns of a series (intensity, Stokes I); 2 (round 4) = the tile is
+// 8 columns x BOTH polarisations of a channel (lanes 0-7 / 8-15 of a DPP row: 64-byte pieces of two planes instead of one
+// 128-byte piece), and what is summed over the 8 columns is |a|^2, |b|^2, Re conj(a) b, Im conj(a) b -- all four Stokes
+// parameters without storing the voltages and without a second tile waiting in registers (the round-3 attempt spilled).
+template <int M, int OP, int R, int DET = 0>
 __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     constexpr int F = kTilePoints / M;
     static_assert(!DET || (OP == OP_TW_INV && F % 16 == 0 && M >= 2 * R && R == 32), "the detect form reduces over the 16 lanes of a DPP row");
+    static_assert(DET != 2 || F == 16, "the pol-pair detect form: 16-column tiles (8 columns x 2 pols)");
+    constexpr int CW = DET == 2 ? F / 2 : F;   // columns n2 of a tile
     constexpr bool PAD = F < 16;
     constexpr int MR = M / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -236,12 +250,15 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
 
     const int tid = threadIdx.x;
     const int f = tid % F, tau = tid / F;
-    const uint32_t ngrp = (uint32_t)(p.N2 / F);
-    const uint32_t ntile = ngrp * (uint32_t)p.S * (uint32_t)p.P;   // (series, row block, column group)
+    const uint32_t ngrp = (uint32_t)(p.N2 / CW);
+    // (DET 2: the "series" of a tile is a channel = a polarisation pair; lanes 8-15 read the second plane)
+    const uint32_t ntile = ngrp * (uint32_t)(DET == 2 ? p.S / 2 : p.S) * (uint32_t)p.P;   // (series, row block, column group)
     const int pitch = p.N2;   // elements between consecutive rows of the planar arrays (a padded pitch was measured: see oop_mode)
-    const int voff = (tau * pitch + f) * (int)sizeof(cf);
+    const int64_t ldp0 = p.ld ? p.ld_plane : p.plane;
+    const int voff = DET == 2 ? (int)(((int64_t)tau * pitch + (f & 7) + (int64_t)(f >> 3) * ldp0) * (int64_t)sizeof(cf))
+                              : (tau * pitch + f) * (int)sizeof(cf);
     const int stepb = MR * pitch * (int)sizeof(cf);
-    const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * pitch + F) * (int64_t)sizeof(cf));
+    const uint32_t tile_bytes = (uint32_t)(((int64_t)(M - 1) * pitch + CW + (DET == 2 ? ldp0 : 0)) * (int64_t)sizeof(cf));
     const int shift = p.tw.shift;
     const int64_t lomask = (1LL << shift) - 1;
     const uint32_t c0 = (uint32_t)p.crop_start, c1 = (uint32_t)p.crop_stop;
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     const cf* ldb = p.ld ? p.ld : p.data;
     const int64_t ldp = p.ld ? p.ld_plane : p.plane;
     auto tile_rsrc = [&](uint32_t t) {   // where tile t is loaded from
-        return t < ntile ? make_rsrc(ldb + (int64_t)series_of(t) * ldp + block_of(t) * blk + (int64_t)group_of(t) * F, tile_bytes)
+        return t < ntile ? make_rsrc(ldb + (int64_t)series_of(t) * (DET == 2 ? 2 : 1) * ldp + block_of(t) * blk + (int64_t)group_of(t) * CW, tile_bytes)
                          : make_rsrc(p.data, 0);
     };
     auto store_rsrc = [&](uint32_t t) {  // where its outputs go (the base may lie before the array when the
@@ -290,7 +307,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
     uint32_t tto = 0;                    // time index of that tile's first sample in this thread (N < 2^31)
     const uint32_t rowstep = (uint32_t)MR * (uint32_t)p.N2;
     double2 zbh, zbl, zsh, zsl;
-    load_tables(g * F + f, block_of(t), zbh, zbl, zsh, zsl);
+    const int fcol = DET == 2 ? (f & 7) : f;   // column of this lane within the tile
+    load_tables(g * CW + fcol, block_of(t), zbh, zbl, zsh, zsl);
     cf v[R], out[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
 
     while (true) {
         launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
-        const int n2 = g * F + f;
+        const int n2 = g * CW + fcol;
         const double2 zb = zmul(zbh, zbl), zs = zmul(zsh, zsl);
         const bool more = tn < ntile;
         // the tile after next: requested now, its index parked in LDS after the butterflies (the atomic's
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
 #pragma unroll
             for (int k = 0; k < n; ++k) {
                 if (cnt < R) {
-                    if constexpr (DET) {
+                    if constexpr (DET != 0) {
                     } else if constexpr (OP == OP_TW_INV) {
                         // cropped samples: an out-of-range offset makes the hardware drop the store (no branch)
                         const uint32_t tt = tto + (uint32_t)cnt * rowstep;
@@ -351,9 +369,47 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         const uint32_t tnn = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]);  // wave-uniform: descriptors stay in SGPRs
         // tables of the next tile: after every request above, before nothing that has to wait for them
         const int gn = more ? group_of(tn) : g;
-        if (more) load_tables(gn * F + f, block_of(tn), zbh, zbl, zsh, zsl);
+        if (more) load_tables(gn * CW + fcol, block_of(tn), zbh, zbl, zsh, zsl);
 #ifndef PBH_F64
-        if constexpr (DET) {
+        if constexpr (DET == 2) {
+            // lanes 0-7: polarisation a, lanes 8-15: polarisation b of the same 8 columns; the partner's value comes over DPP
+            // (row_ror:8).  a-lanes carry |a|^2 and Re conj(a) b, b-lanes |b|^2 and Im conj(a) b; both are summed over the
+            // 8 columns by a transposing reduction (lane fl ends with rows 4 fl .. 4 fl + 3): two 16-byte stores per lane.
+            const int fl = f & 7;
+            const bool polb = (f & 8) != 0;
+            float pw[R], qw[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float wx = dpp_from<0x128>(v[i].x), wy = dpp_from<0x128>(v[i].y);
+                pw[i] = v[i].x * v[i].x + v[i].y * v[i].y;
+                qw[i] = polb ? (wx * v[i].y - wy * v[i].x) : (v[i].x * wx + v[i].y * wy);
+            }
+            const int c8 = g * 8;
+            const int bmod = (int)(p.crop_start % p.det_ns), bcol = bmod & 7;
+            const bool split = bcol != 0 && c8 % p.det_ns == bmod - bcol;   // tile-uniform: a scrunch boundary inside this group
+            const int64_t at = (int64_t)tau * R + 4 * fl;
+            const int64_t chan = series_of(t);
+            const int64_t ng8 = p.N2 / 8, nb = p.N2 / p.det_ns;
+            float4* dp = reinterpret_cast<float4*>(p.det_part + ((chan * 4 + (polb ? 1 : 0)) * ng8 + g) * M + at);
+            float4* dq = reinterpret_cast<float4*>(p.det_part + ((chan * 4 + 2 + (polb ? 1 : 0)) * ng8 + g) * M + at);
+            if (split) {
+                float lo[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) { lo[i] = fl >= bcol ? 0.0f : pw[i]; pw[i] -= lo[i]; }
+                *dp = treduce8x32(lo, fl);
+                const float4 hp = treduce8x32(pw, fl);
+#pragma unroll
+                for (int i = 0; i < R; ++i) { lo[i] = fl >= bcol ? 0.0f : qw[i]; qw[i] -= lo[i]; }
+                *dq = treduce8x32(lo, fl);
+                const float4 hq = treduce8x32(qw, fl);
+                const int64_t sb = c8 / p.det_ns;
+                *reinterpret_cast<float4*>(p.det_side + ((chan * 4 + (polb ? 1 : 0)) * nb + sb) * M + at) = hp;
+                *reinterpret_cast<float4*>(p.det_side + ((chan * 4 + 2 + (polb ? 1 : 0)) * nb + sb) * M + at) = hq;
+            } else {
+                *dp = treduce8x32(pw, fl);
+                *dq = treduce8x32(qw, fl);
+            }
+        } else if constexpr (DET == 1) {
             float pw[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) pw[i] = v[i].x * v[i].x + v[i].y * v[i].y;
@@ -403,7 +459,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colq(ColpParams p) {
         g = gn;
     }
     // drain: the last tile's outputs
-    if constexpr (DET) return;
+    if constexpr (DET != 0) return;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         if constexpr (OP == OP_TW_INV) {

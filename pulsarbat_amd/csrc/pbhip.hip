@@ -244,6 +244,15 @@ static int colp_mode() {
     return m;
 }
 #ifndef PBH_F64
+// the inverse column pass that leaves the four Stokes sums of every 8 columns (tiles of 8 columns x both pols; N1 = 1024)
+static int launch_colq_det4(int M, ColpParams prm, hipStream_t st) {
+    if (M != 1024 || prm.S % 2) return fail(PBH_ERR_UNSUPPORTED, "pol-pair detecting column pass: 1024 rows, polarisation pairs");
+    prm.order = 0;
+    int64_t tiles = (int64_t)(prm.S / 2) * (prm.N2 / 8);
+    if (tiles > row_grid()) tiles = row_grid();
+    if (colp_mode() < 2) prm.counter = nullptr;
+    return launch_tile_kernel(k_colq<1024, OP_TW_INV, PBH_R, 2>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+}
 // the inverse column pass that detects instead of storing (N1 = 64 ... 1024: tiles of 256 ... 16 columns)
 static int launch_colq_det(int M, ColpParams prm, hipStream_t st) {
     const int F = kTilePoints / M;
@@ -252,7 +261,7 @@ static int launch_colq_det(int M, ColpParams prm, hipStream_t st) {
     if (tiles > row_grid()) tiles = row_grid();
     if (colp_mode() < 2) prm.counter = nullptr;
     switch (M) {
-#define X(m) case m: return launch_tile_kernel(k_colq<m, OP_TW_INV, PBH_R, true>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+#define X(m) case m: return launch_tile_kernel(k_colq<m, OP_TW_INV, PBH_R, 1>, prm, tiles, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
         X(64) X(128) X(256) X(512) X(1024)
 #undef X
     }
@@ -835,6 +844,55 @@ static cf* ensure_work2(pbh_plan* p) {
             if (t[i] > tmax) tmax = t[i];
         }
         opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
+    }
+    // All candidates of one class (about every second process): consecutive allocations tend to share it.  One more round
+    // behind a large spacer allocation (a quarter of the free memory, held only while the candidates are made) -- diag switch
+    // PBH_CLASS_SPACER=0 turns it off.
+    static const bool spacer_on = [] { const char* e = diag_env("PBH_CLASS_SPACER"); return e ? atoi(e) != 0 : true; }();
+    if (probe && n > 1 && !opposite && spacer_on) {
+        size_t fr = 0, tot = 0;
+        void* spacer = nullptr;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 8 * bytes && hipMalloc(&spacer, fr / 4) == hipSuccess) {
+            // keep the best so far in slot 0, replace the others
+            std::swap(cand[0], cand[pick]);
+            std::swap(t[0], t[pick]);
+            for (int i = 1; i < n; ++i) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; cand[i] = nullptr; }
+            int m = 1;
+            while (m < NC) {
+                if (dev_alloc(p, &cand[m], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
+                t[m++] = -1.f;
+            }
+            (void)hipFree(spacer);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (m > 1 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                const unsigned grid = (unsigned)(len / 16 / 1024);
+                t[0] = -1.f;
+                for (int rep = 0; rep < 6; ++rep)
+                    for (int i = 0; i < m; ++i) {
+                        (void)hipEventRecord(e0, p->stream);
+                        hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)p->work, (float4*)cand[i], (int64_t)grid * 1024);
+                        (void)hipEventRecord(e1, p->stream);
+                        float ms = 0.f;
+                        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && (t[i] < 0 || ms < t[i]))
+                            t[i] = ms;
+                    }
+            }
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            (void)hipGetLastError();
+            n = m;
+            pick = 0;
+            tmax = -1.f;
+            for (int i = 0; i < n; ++i) {
+                if (t[i] > 0 && (t[pick] < 0 || t[i] < t[pick])) pick = i;
+                if (t[i] > tmax) tmax = t[i];
+            }
+            opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
+            static const bool trace2 = getenv("PBH_TRACE_ALLOC") != nullptr;
+            if (trace2) fprintf(stderr, "[pbhip] work2: second round behind a %.1f-GiB spacer\n", (double)(fr / 4) / 1073741824.0);
+        } else {
+            (void)hipGetLastError();
+        }
     }
     for (int i = 0; i < n; ++i)
         if (i != pick) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; }
@@ -1491,7 +1549,35 @@ std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tai
                     const int nj = ns / 16 + 1, parts = nj <= 9 ? 1 : (nj <= 129 ? 4 : 16), xw = 256 / parts;
                     hipLaunchKernelGGL(k_detect_reduce, dim3((unsigned)((Q + xw - 1) / xw), (unsigned)(N2 / ns), (unsigned)nchan), dim3(256), 0, st,
                                        (const real*)cpd.det_part, (const real*)cpd.det_side, dout, N2, Q, (int)PBH_R, ns, start, nout, nchan, npol, mode,
-                                       parts);
+                                       parts, 16, npol);
+                    HIPCHECK(hipGetLastError());
+                    return (int)PBH_OK;
+                }});
+                det_done = true;
+            }
+        }
+        // Round 4: all four Stokes parameters the same way -- the tile is 8 columns x both polarisations of a channel, the pass
+        // leaves |a|^2, |b|^2, Re / Im conj(a) b summed over every 8 columns (4 x 4 KiB per tile instead of 128 KiB of voltages)
+        // and the reducer assembles I, Q, U, V.  (N1 = 1024; scrunch factors that are multiples of 8 and divide a row.)
+        if (!det_done && tail.out && (tail.mode == PBH_DETECT_STOKES_LINEAR || tail.mode == PBH_DETECT_STOKES_CIRCULAR) && p->npol == 2 &&
+            detect_in_colq() && colp && P == 1 && Q == 1024 && PBH_R == 32 && N2 % tail.nscrunch == 0 && tail.nscrunch % 8 == 0 &&
+            (stop - start) / tail.nscrunch > 0 && N * (int64_t)sizeof(cf) < (1LL << 31)) {
+            const int ns = tail.nscrunch, nchan = p->nchan, npol = p->npol, mode = tail.mode;
+            const size_t npart = (size_t)(S / 2) * 4 * (size_t)(N2 / 8) * (size_t)Q, nside = (size_t)(S / 2) * 4 * (size_t)(N2 / ns) * (size_t)Q;
+            real* part = ensure_det_part(p, (npart + nside) * sizeof(real));
+            if (part) {
+                cp3.det_part = part;
+                cp3.det_side = part + npart;
+                cp3.det_ns = ns;
+                const int64_t nout = (stop - start) / ns;
+                real* dout = tail.out;
+                const ColpParams cpd = cp3;
+                steps.push_back({"k_col_inv", [=](hipStream_t st) { return launch_colq_det4(Q, cpd, st); }});
+                steps.push_back({"k_detect_reduce", [=](hipStream_t st) {
+                    const int nj = ns / 8 + 1, parts = nj <= 9 ? 1 : (nj <= 129 ? 4 : 16), xw = 256 / parts;
+                    hipLaunchKernelGGL(k_detect_reduce, dim3((unsigned)((Q + xw - 1) / xw), (unsigned)(N2 / ns), (unsigned)nchan), dim3(256), 0, st,
+                                       (const real*)cpd.det_part, (const real*)cpd.det_side, dout, N2, Q, (int)PBH_R, ns, start, nout, nchan, npol, mode,
+                                       parts, 8, 4);
                     HIPCHECK(hipGetLastError());
                     return (int)PBH_OK;
                 }});
