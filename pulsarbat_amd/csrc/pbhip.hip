@@ -813,7 +813,8 @@ static cf* ensure_work2(pbh_plan* p) {
     void* cand[NC] = {};
     float t[NC];
     int n = 0;
-    const bool probe = class_probing() && len >= ((size_t)512 << 20);   // (smaller copies live in the Infinity Cache)
+    const bool probe = class_probing() && len >= ((size_t)1 << 30);   // blocks of 1 GiB and more: the candidates cost ~50 ms once
+                                                                       // (a streaming driver's chunk plans are smaller and skip this)
     while (n < (probe ? NC : 1)) {
         if (dev_alloc(p, &cand[n], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
         t[n++] = -1.f;
@@ -845,55 +846,8 @@ static cf* ensure_work2(pbh_plan* p) {
         }
         opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
     }
-    // All candidates of one class (about every second process): consecutive allocations tend to share it.  One more round
-    // behind a large spacer allocation (a quarter of the free memory, held only while the candidates are made) -- diag switch
-    // PBH_CLASS_SPACER=0 turns it off.
-    static const bool spacer_on = [] { const char* e = diag_env("PBH_CLASS_SPACER"); return e ? atoi(e) != 0 : true; }();
-    if (probe && n > 1 && !opposite && spacer_on) {
-        size_t fr = 0, tot = 0;
-        void* spacer = nullptr;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 8 * bytes && hipMalloc(&spacer, fr / 4) == hipSuccess) {
-            // keep the best so far in slot 0, replace the others
-            std::swap(cand[0], cand[pick]);
-            std::swap(t[0], t[pick]);
-            for (int i = 1; i < n; ++i) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; cand[i] = nullptr; }
-            int m = 1;
-            while (m < NC) {
-                if (dev_alloc(p, &cand[m], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
-                t[m++] = -1.f;
-            }
-            (void)hipFree(spacer);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (m > 1 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                const unsigned grid = (unsigned)(len / 16 / 1024);
-                t[0] = -1.f;
-                for (int rep = 0; rep < 6; ++rep)
-                    for (int i = 0; i < m; ++i) {
-                        (void)hipEventRecord(e0, p->stream);
-                        hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)p->work, (float4*)cand[i], (int64_t)grid * 1024);
-                        (void)hipEventRecord(e1, p->stream);
-                        float ms = 0.f;
-                        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && (t[i] < 0 || ms < t[i]))
-                            t[i] = ms;
-                    }
-            }
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-            (void)hipGetLastError();
-            n = m;
-            pick = 0;
-            tmax = -1.f;
-            for (int i = 0; i < n; ++i) {
-                if (t[i] > 0 && (t[pick] < 0 || t[i] < t[pick])) pick = i;
-                if (t[i] > tmax) tmax = t[i];
-            }
-            opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
-            static const bool trace2 = getenv("PBH_TRACE_ALLOC") != nullptr;
-            if (trace2) fprintf(stderr, "[pbhip] work2: second round behind a %.1f-GiB spacer\n", (double)(fr / 4) / 1073741824.0);
-        } else {
-            (void)hipGetLastError();
-        }
-    }
+    // (A second round of candidates behind a spacer allocation of a quarter of the free memory was tried for the processes
+    //  whose six candidates share one class: the 60-GiB hipMalloc alone takes 1.9 s -- not worth 4 %.)
     for (int i = 0; i < n; ++i)
         if (i != pick) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; }
     p->work2 = (cf*)cand[pick];
@@ -1092,9 +1046,9 @@ static int fd4_roles(pbh_plan* p, const cf* in, cf* out, const DetectTail& tail,
         if (e.in == in && e.out == okey && e.in) return e.swap;
     // bit 0: the Q4 intermediate lives in work2 (else in work); bit 1: the inverse column pass runs out of place, back into
     // the buffer the Q4 intermediate left (else in place on the planar one)
-    // A caller that hands over a fresh output array at every call (results kept in a list) shows a new pair each time: only
-    // the first kRoleTunes pairs of a plan are timed (8 extra runs each), later ones take the last decision as it stands.
-    constexpr int kRoleTunes = 3;
+    // All one-time work belongs to a plan's FIRST call: only the first pair of a plan is timed (8 extra runs), later pairs
+    // -- a caller that hands over a fresh output array at every call shows a new one each time -- take that decision as it stands.
+    constexpr int kRoleTunes = 1;
     int swap = p->role_last;
     const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
     if (class_probing() && bytes >= ((size_t)1 << 30) && p->stop > p->start && p->role_tunes < kRoleTunes) {
