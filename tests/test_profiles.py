@@ -23,3 +23,29 @@ def test_rocprof_agrees_with_bench_line():
     assert abs(roof["traffic"] - traffic["k_row_fused"]) / traffic["k_row_fused"] < 0.02
     # the five kernels of the step add up to the step
     assert abs(bench["path_roofline"]["kernel_ms_total"] - bench["ms_per_step"]) / bench["ms_per_step"] < 0.05
+
+
+def test_round4_records_agree():
+    """Round 4: the default bench line, the rocprofv3 summary and traffic.json of ONE lease (profiles/r04_bench_default.json,
+    r04_fd4_kernel_stats.csv, traffic.json): the dominant kernel's fraction follows from the tracked trace to within 3 %
+    (`roofline.frac_rocprof`), the four kernels add up to the step, the measured HBM traffic is the algorithmic one."""
+    bench = json.loads(open(os.path.join(P, "r04_bench_default.json")).read().strip().splitlines()[-1])
+    roof, path = bench["roofline"], bench["path_roofline"]
+    assert list(path["kernel_ms"]) == ["k_col_fwd", "k_row_fused", "k_col_inv", "k_reinterleave"]     # four passes
+    assert roof["kernel"] == "k_col_fwd" and roof["frac_rocprof"] is not None
+    assert abs(roof["frac_rocprof"] - roof["frac"]) / roof["frac"] < 0.03
+    traffic = json.load(open(os.path.join(P, "traffic.json")))
+    rows = list(csv.DictReader(open(os.path.join(P, "r04_fd4_kernel_stats.csv"))))
+    colfd = [r for r in rows if "k_colfd<" in r["Name"]]
+    assert len(colfd) == 1
+    avg_us = float(colfd[0]["AverageNs"]) / 1e3
+    # (traffic.json's figure drops the first launches of the process: they hold the first-call timing of the buffer roles)
+    assert abs(avg_us - traffic["_kernel_us"]["k_col_fwd"]) / avg_us < 0.05
+    assert abs(avg_us / 1e3 - roof["ms_per_launch"]) / roof["ms_per_launch"] < 0.05
+    assert 0.98 < traffic["k_col_fwd"] / roof["alg_bytes_per_launch"] < 1.03        # every input line fetched once (gang scheduling)
+    assert abs(path["kernel_ms_total"] - bench["ms_per_step"]) / bench["ms_per_step"] < 0.03
+    assert abs(bench["ms_per_step_event_median"] - bench["ms_per_step"]) / bench["ms_per_step"] < 0.02
+    assert bench["ms_per_step"] < 3.75 and path["frac"] > 0.61                      # the round's bar
+    assert path["copy_ceiling_GBps"] > 5500 and path["rmw_ceiling_GBps"] > 5300    # the repaired yardstick
+    full = bench["configs3_stream_full"]
+    assert full["ms_total"] < 900 and abs(full["h2d_GB"] - full["input_GB"]) / full["input_GB"] < 0.001

@@ -17,7 +17,7 @@ def main():
         if args[0] == "--rounds":
             rounds = int(args[1]); args = args[2:]
         elif args[0] == "--bench-args":
-            bargs = args[1].split(); args = args[2:]
+            bargs = args[1].replace("+", " ").split(); args = args[2:]   # items joined by + (or spaces)
         else:
             sys.exit("unknown option " + args[0])
     res = {c: [] for c in args}
