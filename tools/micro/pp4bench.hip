@@ -337,6 +337,73 @@ __global__ __launch_bounds__(512) void k_fdq(const float2* __restrict__ in, floa
     if (MODE == 1 && acc == 123.456f) sink[0] = acc;
 }
 
+
+// fdq with 16-byte memory instructions (round 4, after the four-pass schedule was in): the same pieces and lines as k_fdq
+// (32-byte pieces of the caller's lines in, whole Q4 lines out, gang of 4), but LW / SW = bytes per lane of the loads / stores.
+//   LW 16: lanes (2 l, 2 l + 1) take the two halves of a piece -- 32 pieces per wave instruction instead of 16, half the instructions
+//   SW 16: a lane stores columns (c, c + 1) of one series -- 8 lines per wave instruction instead of 4
+// (the real kernel would pay a lane-pair exchange for either: v_permlane32_swap, one per float)
+template <int MODE, int LW, int SW>
+__global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, float2* __restrict__ out, float* sink) {
+    const int tid = threadIdx.x;
+    const uint32_t b = blockIdx.x, xg = b & 7u, li = b >> 3;
+    const uint32_t gang = xg * 8 + (li >> 2), member = li & 3;    // 64 gangs of 4
+    constexpr uint32_t NG = N2 / 4;
+    constexpr int NLD = LW == 16 ? 16 : 32, NST = SW == 16 ? 16 : 32;
+    int voff_in, voff_out;
+    if (LW == 16) { const int h = tid & 1, c = (tid >> 1) & 3, t = tid >> 3; voff_in = ((t * N2 + c) * S + 2 * h) * 8; }
+    else          { const int ser = tid & 3, c = (tid >> 2) & 3, t = tid >> 4; voff_in = ((t * N2 + c) * S + ser) * 8; }
+    if (SW == 16) { const int cp = tid & 1, ser = (tid >> 1) & 3, k = tid >> 3; voff_out = (k * 4 * N2 + ser * 4 + cp * 2) * 8; }
+    else          { const int c = tid & 3, ser = (tid >> 2) & 3, k = tid >> 4; voff_out = (k * 4 * N2 + ser * 4 + c) * 8; }
+    constexpr uint32_t SIN = (uint32_t)(1024 / NLD) * N2 * S * 8, SOUT = (uint32_t)(1024 / NST) * 4 * N2 * 8;
+    constexpr uint32_t in_span = (uint32_t)(((int64_t)(N1 - 1) * N2 * S + 3 * S + 4) * 8);
+    constexpr uint32_t out_span = (uint32_t)(((int64_t)(N1 - 1) * 4 * N2 + 16) * 8);
+    auto in_rsrc = [&](uint32_t k) {
+        const uint32_t g = k * 64 + gang;
+        if (g >= NG) return make_rsrc(in, 0);
+        return make_rsrc(in + ((int64_t)g * 4 * S + 4 * member), in_span);
+    };
+    auto out_rsrc = [&](uint32_t k) {
+        const uint32_t g = k * 64 + gang;
+        if (g >= NG) return make_rsrc(out, 0);
+        return make_rsrc(out + ((int64_t)member * N1 * 4 * N2 + (int64_t)g * 16), out_span);
+    };
+    float v[64], nx[64];
+    float acc = 0.f;
+    auto load_all = [&](rsrc_t rd, float* d) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (LW == 16) { u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rd, voff_in, (int)(i * SIN), 0); d[4 * i] = __uint_as_float(x.x); d[4 * i + 1] = __uint_as_float(x.y); d[4 * i + 2] = __uint_as_float(x.z); d[4 * i + 3] = __uint_as_float(x.w); }
+            else { u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rd, voff_in, (int)(i * SIN), 0); d[2 * i] = __uint_as_float(x.x); d[2 * i + 1] = __uint_as_float(x.y); }
+        }
+    };
+    if (MODE != 2) load_all(in_rsrc(0), v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = (float)(tid + i);
+    }
+    for (uint32_t k = 0; k * 64 + gang < NG; ++k) {
+        const rsrc_t rdn = in_rsrc(k + 1);
+        const rsrc_t wr = out_rsrc(k);
+        // stores and loads interleaved in proportion (as the kernels pace them)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (MODE != 1) {
+                if (SW == 16) { if (i % 2 == 0) { u32x4 y; y.x = __float_as_uint(v[2 * i] + 1.f); y.y = __float_as_uint(v[2 * i + 1]); y.z = __float_as_uint(v[2 * i + 2]); y.w = __float_as_uint(v[2 * i + 3]);
+                                                  __builtin_amdgcn_raw_buffer_store_b128(y, wr, voff_out, (int)((i / 2) * SOUT), 0); } }
+                else { u32x2 y; y.x = __float_as_uint(v[2 * i] + 1.f); y.y = __float_as_uint(v[2 * i + 1]); __builtin_amdgcn_raw_buffer_store_b64(y, wr, voff_out, (int)(i * SOUT), 0); }
+            } else acc += v[2 * i] + v[2 * i + 1];
+            if (MODE != 2) {
+                if (LW == 16) { if (i % 2 == 0) { const int j = i / 2; u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rdn, voff_in, (int)(j * SIN), 0); nx[4 * j] = __uint_as_float(x.x); nx[4 * j + 1] = __uint_as_float(x.y); nx[4 * j + 2] = __uint_as_float(x.z); nx[4 * j + 3] = __uint_as_float(x.w); } }
+                else { u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rdn, voff_in, (int)(i * SIN), 0); nx[2 * i] = __uint_as_float(x.x); nx[2 * i + 1] = __uint_as_float(x.y); }
+            } else { nx[2 * i] = v[2 * i] + 1.f; nx[2 * i + 1] = v[2 * i + 1]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = nx[i];
+    }
+    if (MODE == 1 && acc == 123.456f) sink[0] = acc;
+}
+
 // row pass over Q4: a workgroup takes a channel (both pols one after the other, one phase row), 32-byte pieces of every line
 template <int LAY, int SCHED>   // SCHED 0: gang of 2 static (the two channels of a pair side by side), 1: global counter, channel fastest
 __global__ __launch_bounds__(512) void k_rowq(const float2* __restrict__ src, float2* __restrict__ dst, const float* __restrict__ phase, unsigned* counters) {
@@ -691,6 +758,22 @@ int main(int argc, char** argv) {
             timeit(nm, two, [&] { hipLaunchKernelGGL((k_fdq<0, 0, 0>), dim3(256), dim3(512), 0, 0, in, aa, cnt, (float*)cnt); });
             snprintf(nm, 96, "shift %9zu: rowq4 (a shifted -> b)", sh);
             timeit(nm, rowb + bytes / 4.0, [&] { hipLaunchKernelGGL((k_rowq4<1>), dim3(256), dim3(512), 0, 0, aa, b, ph); });
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "--widths")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            timeit("fdq x2 loads, x2 stores (k_fdq)", two, [&] { hipLaunchKernelGGL((k_fdq<0, 0, 0>), dim3(256), dim3(512), 0, 0, in, a, cnt, (float*)cnt); });
+#define W(M, L, St, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, L, St>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
+            W(0, 8, 8, "fdqw  8-byte loads,  8-byte stores", two)
+            W(0, 16, 8, "fdqw 16-byte loads,  8-byte stores", two)
+            W(0, 8, 16, "fdqw  8-byte loads, 16-byte stores", two)
+            W(0, 16, 16, "fdqw 16-byte loads, 16-byte stores", two)
+            W(1, 8, 8, "fdqw  8-byte loads only", 1.0 * bytes)
+            W(1, 16, 8, "fdqw 16-byte loads only", 1.0 * bytes)
+            W(2, 8, 8, "fdqw  8-byte stores only", 1.0 * bytes)
+            W(2, 8, 16, "fdqw 16-byte stores only", 1.0 * bytes)
+#undef W
         }
         return 0;
     }
