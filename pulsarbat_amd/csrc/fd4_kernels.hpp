@@ -58,7 +58,9 @@ struct ColfdParams {
 // SP (memory instructions over the iteration; the pass is bound by the CU's address path, which must never run dry):
 //   0 = two (store, load) pairs per tick until all 32 are out (k_colq's pacing: they are gone after 16 of the 24 ticks),
 //   1 = one pair per tick, the last eight between the twiddle products: requests are issued until the iteration ends
-template <int M, int R, int SP = 0>
+//   2 = nothing deferred: the ticks carry the next tile's loads only, every output is stored as soon as its twiddle product exists
+//       (the address path works on the stores while the next transform starts; in2 needs no register an output still holds)
+template <int M, int R, int SP = 2>
 __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     constexpr int F = kTilePoints / M;   // columns of a tile: 4 series x C columns n2
     constexpr int C = F / 4;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
 #pragma unroll
             for (int k = 0; k < n; ++k) {
                 if (cnt < R) {
-                    buf_store(rdo, voff_out, (int)(cnt * step_out), out[cnt]);
+                    if constexpr (SP != 2) buf_store(rdo, voff_out, (int)(cnt * step_out), out[cnt]);
                     in2[cnt] = buf_load(rd2, voff_in, (int)(cnt * step_in));
                     ++cnt;
                 }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
             }
         };
         fft_tile<M, 1, R, -1, F, false, false, false>(v, lds, tau, f, w, hk);
-        if constexpr (SP == 0) pump(R);  // whatever the ticks did not reach (short transforms)
+        if constexpr (SP == 0 || SP == 2) pump(R);  // whatever the ticks did not reach (short transforms)
         else {
             constexpr int LEFT = 8;       // pairs kept for the twiddle products below (out[i] is stored before it is rewritten)
 #pragma unroll
@@ -149,21 +151,23 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
                 if (cnt < R - LEFT) pump(1);
         }
         // tables of the next tile: after every request above
-        if (more && SP == 0) load_tables((int)gn * C + c, zbh, zbl, zsh, zsl);
+        if (more && SP != 1) load_tables((int)gn * C + c, zbh, zbl, zsh, zsl);
+        if constexpr (SP == 2) rdo = out_rsrc(g);
         double2 z = zb;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             if constexpr (SP != 0) {
-                if (i % 3 == 0 && cnt < R) {
+                if (SP == 1 && i % 3 == 0 && cnt < R) {
                     __builtin_amdgcn_sched_barrier(0x38E);
                     pump(1);
                     __builtin_amdgcn_sched_barrier(0x38E);
                 }
             }
             out[i] = cmul(v[i], make_cf((real)z.x, (real)z.y));
+            if constexpr (SP == 2) buf_store(rdo, voff_out, (int)(i * step_out), out[i]);
             z = zmul(z, zs);
         }
-        if constexpr (SP != 0) {
+        if constexpr (SP == 1) {
             pump(R);
             if (more) load_tables((int)gn * C + c, zbh, zbl, zsh, zsl);
         }
@@ -173,8 +177,10 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
         for (int i = 0; i < R; ++i) v[i] = in2[i];
         g = gn;
     }
+    if constexpr (SP != 2) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) buf_store(rdo, voff_out, (int)(i * step_out), out[i]);
+        for (int i = 0; i < R; ++i) buf_store(rdo, voff_out, (int)(i * step_out), out[i]);
+    }
 }
 
 // Fused row pass over Q4 rows: k_rowp16 (kernels.hpp) with one SERIES per tile instead of a polarisation pair, because the

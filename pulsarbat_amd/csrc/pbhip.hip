@@ -433,10 +433,11 @@ static int gang_grid(int members, int64_t units) {
 static int launch_colfd(int M, const ColfdParams& prm, hipStream_t st) {
     const int NQ = prm.S / 4, C = (kTilePoints / M) / 4;
     const int grid = gang_grid(NQ, prm.N2 / C);
-    const int sp = fd4_sp() / 10;
+    const int sp = fd4_sp() / 10;   // A/B (diagnostic builds): 0 = stores as soon as the outputs exist (default), 1 = spread pairs, 2 = deferred stores
     switch (M) {
-#define X(m) case m: return sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
-                                    : launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+#define X(m) case m: return sp == 2 ? launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                         : sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                                    : launch_tile_kernel(k_colfd<m, PBH_R, 2>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
         X(64) X(128) X(256) X(512) X(1024)
 #undef X
     }

@@ -26,7 +26,7 @@ step_pp4bench()   { tools/micro/bin/pp4bench; }
 step_micro()      { tools/micro/bin/$ARG; }                                     # micro:SECONDS:name
 step_placement()  { PBH_TRACE_ALLOC=1 python tools/exp_placement.py $ARG; }
 step_py()         { python $ARG; }                                              # py:SECONDS:script args (use , for spaces)
-step_ab()         { tools/ab.sh $ARG; }
+step_ab()         { python tools/ab_env.py $ARG; }                                  # ab:SECONDS:--rounds,3,-,NAME=VAL fresh processes
 # N fresh processes of the headline bench: the per-process spread (round 3: 2.5 % on one box)
 step_spread()     { for i in $(seq 1 ${ARG:-5}); do python bench.py --no-extras --no-cpu --no-series 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), round(d['ms_per_step_event_median'],4), d['path_roofline']['kernel_ms'], round(d['path_roofline'].get('copy_ceiling_GBps',0)), round(d['path_roofline'].get('rmw_ceiling_GBps',0)))" || return 1; done; }
 step_first8()     { tools/first_8gpu.sh; }

@@ -343,7 +343,10 @@ __global__ __launch_bounds__(512) void k_fdq(const float2* __restrict__ in, floa
 //   LW 16: lanes (2 l, 2 l + 1) take the two halves of a piece -- 32 pieces per wave instruction instead of 16, half the instructions
 //   SW 16: a lane stores columns (c, c + 1) of one series -- 8 lines per wave instruction instead of 4
 // (the real kernel would pay a lane-pair exchange for either: v_permlane32_swap, one per float)
-template <int MODE, int LW, int SW>
+// SUB = log2 of the columns of a sub-block: the same pieces with the rows of a tile 2^SUB x 128 B apart instead of 2 MiB (sub-blocks of
+// (1024, 2^SUB, 16)): is the cost of a
+// partial-line load the LINE, or the 2-MiB page each of its rows lives in?
+template <int MODE, int LW, int SW, int SUB = 0>
 __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, float2* __restrict__ out, float* sink) {
     const int tid = threadIdx.x;
     const uint32_t b = blockIdx.x, xg = b & 7u, li = b >> 3;
@@ -351,16 +354,18 @@ __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, flo
     constexpr uint32_t NG = N2 / 4;
     constexpr int NLD = LW == 16 ? 16 : 32, NST = SW == 16 ? 16 : 32;
     int voff_in, voff_out;
-    if (LW == 16) { const int h = tid & 1, c = (tid >> 1) & 3, t = tid >> 3; voff_in = ((t * N2 + c) * S + 2 * h) * 8; }
-    else          { const int ser = tid & 3, c = (tid >> 2) & 3, t = tid >> 4; voff_in = ((t * N2 + c) * S + ser) * 8; }
+    constexpr int N2E = SUB ? (1 << SUB) : N2;
+    if (LW == 16) { const int h = tid & 1, c = (tid >> 1) & 3, t = tid >> 3; voff_in = ((t * N2E + c) * S + 2 * h) * 8; }
+    else          { const int ser = tid & 3, c = (tid >> 2) & 3, t = tid >> 4; voff_in = ((t * N2E + c) * S + ser) * 8; }
     if (SW == 16) { const int cp = tid & 1, ser = (tid >> 1) & 3, k = tid >> 3; voff_out = (k * 4 * N2 + ser * 4 + cp * 2) * 8; }
     else          { const int c = tid & 3, ser = (tid >> 2) & 3, k = tid >> 4; voff_out = (k * 4 * N2 + ser * 4 + c) * 8; }
-    constexpr uint32_t SIN = (uint32_t)(1024 / NLD) * N2 * S * 8, SOUT = (uint32_t)(1024 / NST) * 4 * N2 * 8;
-    constexpr uint32_t in_span = (uint32_t)(((int64_t)(N1 - 1) * N2 * S + 3 * S + 4) * 8);
+    constexpr uint32_t SIN = (uint32_t)(1024 / NLD) * N2E * S * 8, SOUT = (uint32_t)(1024 / NST) * 4 * N2 * 8;
+    constexpr uint32_t in_span = (uint32_t)(((int64_t)(N1 - 1) * N2E * S + 3 * S + 4) * 8);
     constexpr uint32_t out_span = (uint32_t)(((int64_t)(N1 - 1) * 4 * N2 + 16) * 8);
     auto in_rsrc = [&](uint32_t k) {
         const uint32_t g = k * 64 + gang;
         if (g >= NG) return make_rsrc(in, 0);
+        if (SUB) return make_rsrc(in + ((int64_t)(g / (N2E / 4)) * N1 * N2E * S + (int64_t)(g % (N2E / 4)) * 4 * S + 4 * member), in_span);
         return make_rsrc(in + ((int64_t)g * 4 * S + 4 * member), in_span);
     };
     auto out_rsrc = [&](uint32_t k) {
@@ -773,6 +778,19 @@ int main(int argc, char** argv) {
             W(1, 16, 8, "fdqw 16-byte loads only", 1.0 * bytes)
             W(2, 8, 8, "fdqw  8-byte stores only", 1.0 * bytes)
             W(2, 8, 16, "fdqw 16-byte stores only", 1.0 * bytes)
+#define W1(SB, M, L, St, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, L, St, SB>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
+            W1(6, 1, 8, 8, "rows   8 KiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(8, 1, 8, 8, "rows  32 KiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(10, 1, 8, 8, "rows 128 KiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(11, 1, 8, 8, "rows 256 KiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(12, 1, 8, 8, "rows 512 KiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(13, 1, 8, 8, "rows   1 MiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(14, 1, 8, 8, "rows   2 MiB apart: 8-byte loads only", 1.0 * bytes)
+            W1(8, 0, 8, 8, "rows  32 KiB apart: 8-byte loads, 8-byte stores", two)
+            W1(10, 0, 8, 8, "rows 128 KiB apart: 8-byte loads, 8-byte stores", two)
+            W1(12, 0, 8, 8, "rows 512 KiB apart: 8-byte loads, 8-byte stores", two)
+            W1(13, 0, 8, 8, "rows   1 MiB apart: 8-byte loads, 8-byte stores", two)
+#undef W1
 #undef W
         }
         return 0;
