@@ -54,12 +54,14 @@ struct ColfdParams {
 };
 
 // Forward column pass: M-point FFT over n1 of x[(N2 n1 + n2) S + s], * W_N^{n2 k1}, stored in Q4 order.
-// Structure = k_colq (deferred stores, two memory instructions per tick) with a static, gang-scheduled tile order.
-// SP (memory instructions over the iteration; the pass is bound by the CU's address path, which must never run dry):
-//   0 = two (store, load) pairs per tick until all 32 are out (k_colq's pacing: they are gone after 16 of the 24 ticks),
-//   1 = one pair per tick, the last eight between the twiddle products: requests are issued until the iteration ends
-//   2 = nothing deferred: the ticks carry the next tile's loads only, every output is stored as soon as its twiddle product exists
-//       (the address path works on the stores while the next transform starts; in2 needs no register an output still holds)
+// Structure = k_colq with a static, gang-scheduled tile order.  SP = where the memory instructions go (the pass is bound by the
+// CU's address path: 11.7 us of loads + 7.6 us of stores per tile against 8 us of arithmetic; profiles/r04_ab_colfd_pacing.txt):
+//   2 (default) = the ticks carry the next tile's loads only, ONE per tick (24 of the 32; the rest right after the transform), and
+//       every output is stored as soon as its twiddle product exists: the stores drain while the next transform starts and its
+//       loads trickle in behind them -- 1.18 ms at config 2.  Two loads per tick: 1.34; loads from tick 4 on or the last eight
+//       between the stores: 1.22; every second tick: 1.18; no loads inside the transform: 1.27
+//   0 = k_colq's pacing: stores deferred into the next transform, two (store, load) pairs per tick -- 1.34 ms
+//   1 = one deferred pair per tick, the last eight between the twiddle products -- 1.38 ms
 template <int M, int R, int SP = 2>
 __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     constexpr int F = kTilePoints / M;   // columns of a tile: 4 series x C columns n2
@@ -201,7 +203,9 @@ struct RowqParams {
 // in the first ticks of the INVERSE transform) the next forward transform waits for them with the VALU idle: 18.4 us per
 // tile.  FWD_LOADS of the next tile's 16 loads therefore ride in the FORWARD transform (registers: while the phase row is
 // live only half a tile fits next to the tile in work), the rest in the inverse one, both spread over the ticks.
-//   FWD_LOADS = 0: k_rowp16's pacing, 1.16-1.18 ms at config 2; 4: 1.11-1.15; 8: 1.08-1.10; 10 (default, 256 VGPRs): 1.04-1.08.
+//   FWD_LOADS = 0: k_rowp16's pacing, 1.16-1.18 ms at config 2; 4: 1.11-1.15; 8: 1.08-1.10; 10 (default, 256 VGPRs): 1.04-1.08; 12: 1.11.
+//   Issuing the ten EARLIER (every 2nd / 3rd tick instead of every 4th): 1.19 / 1.13; the phase row requested inside the forward
+//   transform instead of before it: no change (profiles/r04_ab_row_pacing2.txt).
 template <int R, int FWD_LOADS = 10>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowq16(RowqParams p) {
     constexpr int M = kTilePoints;

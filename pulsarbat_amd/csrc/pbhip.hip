@@ -433,11 +433,15 @@ static int gang_grid(int members, int64_t units) {
 static int launch_colfd(int M, const ColfdParams& prm, hipStream_t st) {
     const int NQ = prm.S / 4, C = (kTilePoints / M) / 4;
     const int grid = gang_grid(NQ, prm.N2 / C);
-    const int sp = fd4_sp() / 10;   // A/B (diagnostic builds): 0 = stores as soon as the outputs exist (default), 1 = spread pairs, 2 = deferred stores
     switch (M) {
-#define X(m) case m: return sp == 2 ? launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
-                         : sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
-                                    : launch_tile_kernel(k_colfd<m, PBH_R, 2>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+#ifdef PBH_DIAGNOSTIC
+#define X(m) case m: { const int sp = fd4_sp() / 10;   /* A/B: 0 = stores as soon as the outputs exist (default), 1 = spread pairs, 2 = deferred stores */ \
+            return sp == 2 ? launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                 : sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                           : launch_tile_kernel(k_colfd<m, PBH_R, 2>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16); }
+#else
+#define X(m) case m: return launch_tile_kernel(k_colfd<m, PBH_R, 2>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16);
+#endif
         X(64) X(128) X(256) X(512) X(1024)
 #undef X
     }
@@ -445,11 +449,13 @@ static int launch_colfd(int M, const ColfdParams& prm, hipStream_t st) {
 }
 static int launch_rowq(const RowqParams& prm, hipStream_t st) {
     const int grid = gang_grid(4, (int64_t)(prm.S / 4) * prm.N1);
+#ifdef PBH_DIAGNOSTIC
     switch (fd4_sp() % 10) {   // A/B: loads of the next tile that ride in the forward transform (default 10 of 16)
         case 1: return launch_tile_kernel(k_rowq16<PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         case 2: return launch_tile_kernel(k_rowq16<PBH_R, 4>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
         case 3: return launch_tile_kernel(k_rowq16<PBH_R, 8>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
     }
+#endif
     return launch_tile_kernel(k_rowq16<PBH_R, 10>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
 }
 // geometry the four-pass schedule covers: quads of series, one row tile per row, 1024-row column tiles whose 2-GiB span of

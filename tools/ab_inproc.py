@@ -30,6 +30,10 @@ def main():
     delay = 4.148808e3 * dm * abs((fc / 1e6 - 200.0) ** -2 - (fc / 1e6 + 200.0) ** -2)
     crop = min(int(delay * sr) + 1, n // 2)
     names_all = sorted({kv.split("=", 1)[0] for c in args if c != "-" for kv in c.split("+")})
+    for mode in ("copy", "rmw"):
+        ms = _hip.stream_bench(1 << 31, 10, 0, mode)
+        print(f"yardstick {mode}: {(2 << 31) / ms * 1e-6:.0f} GB/s", flush=True)
+    os.environ.setdefault("PBH_TRACE_ALLOC", "1")
     with _hip.Plan(n, nchan, npol, 0, n - crop) as plan:
         plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, fc)
         xd = DeviceArray.from_host(x)
