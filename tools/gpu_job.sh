@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 
 declare -A DEF=(
   [suite]=1000 [bench]=240 [bench_full]=420 [prof]=420 [pp4bench]=120 [placement]=240 [micro]=120 [gpu_tests_fast]=600
-  [ab]=420 [spread]=300 [pmcmicro]=200 [sh]=300 [pmcbench]=200 [first8]=900 [test]=600 [py]=300 [sharded]=600
+  [ab]=420 [adopt]=10 [spread]=300 [pmcmicro]=200 [sh]=300 [pmcbench]=200 [first8]=900 [test]=600 [py]=300 [sharded]=600
 )
 step_suite()      { python -m pytest tests -x -q -m gpu; }
 step_gpu_tests_fast() { python -m pytest tests -x -q -m gpu -k "not full_size and not fuzz"; }
@@ -22,6 +22,8 @@ step_sharded()    { python -m pytest -x -q -m gpu tests/test_gpu_sharded.py; }
 step_bench()      { python bench.py --no-extras --no-cpu --no-series $ARG | tee "$OUT/bench_line.json"; }
 step_bench_full() { python bench.py $ARG | tee "$OUT/bench_full.json"; }
 step_prof()       { tools/prof.sh "$TAG" $ARG && python tools/prof_summary.py "gpurun_out/prof_$TAG" > "$OUT/prof_summary.txt" && python tools/make_traffic.py "gpurun_out/prof_$TAG" "$OUT/traffic.json"; }
+# after `prof`: make this lease's traffic.json the one bench.py reads (roofline.traffic, frac_rocprof) -- same box, same build
+step_adopt()      { cp "$OUT/traffic.json" profiles/traffic.json; }
 step_pp4bench()   { tools/micro/bin/pp4bench; }
 step_micro()      { tools/micro/bin/$ARG; }                                     # micro:SECONDS:name
 step_placement()  { PBH_TRACE_ALLOC=1 python tools/exp_placement.py $ARG; }
