@@ -310,31 +310,16 @@ class Plan:
         return self.crop_stop - self.crop_start
 
     def _empty_like_class(self, oshape, x):
-        """Output array of the input's allocation class where that can be told and arranged (pbh_plan_buffer_class: the
-        passes then all stream between allocations of different class).  Candidates of the wrong class are kept alive
-        while the next one is allocated, so that the allocator hands out a different block, and go back to its cache."""
+        """Output array of a call.  (Round 4 placed it by allocation class here; the library now picks its second work
+        buffer so that it streams fast from and to BOTH of the caller's arrays on a plan's first call -- ``ensure_work2`` in
+        ``csrc/pbhip.hip`` -- and the output is taken as the allocator hands it out.)"""
         from .device import DeviceArray
-        out = DeviceArray.empty(oshape, self.dtype, device=self.device)
-        # (one-time work belongs to the plan's first call: later calls take the allocator's block as it comes)
-        if self.dtype != np.complex64 or int(np.prod(oshape)) * 8 < (1 << 30) or getattr(self, "_placed", False):
-            return out
-        self._placed = True
-        want = self.buffer_class(x)
-        if want < 0:
-            return out
-        held = []
-        for _ in range(3):
-            if self.buffer_class(out) in (want, -1):
-                break
-            held.append(out)
-            out = DeviceArray.empty(oshape, self.dtype, device=self.device)
-        del held
-        return out
+        return DeviceArray.empty(oshape, self.dtype, device=self.device)
 
     def buffer_class(self, x):
-        """Allocation class of a device array relative to the plan's work buffer (pbh_plan_buffer_class): 0, 1, or -1 when
-        it cannot be told.  Streaming passes are ~5 % faster between allocations of different class; give the input and the
-        output of a repeated call the same class (bench.py allocates its output that way)."""
+        """Allocation class of a device array relative to the plan's two work buffers (pbh_plan_buffer_class): 0 = that of
+        the first, 1 = that of the second, -1 = neither or not told apart.  A streaming pass is ~5 % slower between two
+        allocations of one class; the library arranges its own buffers around the caller's (DESIGN.md 6d d)."""
         self._sync_stream()
         cls = C.c_int(-1)
         nbytes = int(np.prod(x.shape)) * np.dtype(x.dtype).itemsize

@@ -808,69 +808,94 @@ static bool class_probing() {   // PBH_CLASS=0: take allocations as they come (A
     return e ? atoi(e) != 0 : true;
 }
 constexpr float kClassGap = 0.02f;   // relative difference of the two copies below which a probe decides nothing
-// second work buffer, of the class opposite to `work`'s where that can be arranged: up to six candidates are allocated and
-// held, full-size copies work -> candidate timed round robin (the fastest of five each), and the candidate with the fastest
-// copy kept -- "opposite" when it beats the slowest by 2.5 % (two groups exist among the candidates).  ~12 GiB are held for
-// the ~40 ms this takes; with PBH_CLASS=0, or for blocks under 512 MiB, the first allocation is taken as it comes.
-static cf* ensure_work2(pbh_plan* p) {
+// Second work buffer, chosen so that no pass of the four-/five-pass schedules streams between two allocations of one class.
+// What the classes are (tools/micro/classprobe2.hip, profiles/r04_classprobe2_blocks.txt): consecutive 2-GiB allocations of a
+// process keep one class for runs of 4 or 16 blocks (8 / 32 GiB of the physical heap), at least three classes exist, and a copy is
+// slow (0.76-0.78 ms per 2 GiB instead of 0.72-0.74) exactly when source and destination are of the SAME class -- as it is, by
+// definition, inside one allocation.  So: a 4-GiB reference allocation gives the slow time (first half -> second half), and
+// candidates are allocated one after the other (all held, so that the allocator walks on through its heap) until one copies fast
+// from `work`, from the caller's input and from the caller's output (read only: nothing of the caller's is written); at most
+// 16 of them and never more than a quarter of the free memory (32 GiB held for ~0.2 s in the worst case at 2 GiB per block).  With PBH_CLASS=0, or
+// for blocks under 1 GiB (a streaming driver's chunk plans), the first allocation is taken as it comes.
+static cf* ensure_work2(pbh_plan* p, const void* in, const void* out, size_t out_bytes) {
     if (p->work2 || !p->work) return p->work2;
     const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
     const size_t len = bytes & ~(size_t)16383;
-    constexpr int NC = 6;
-    void* cand[NC] = {};
-    float t[NC];
-    int n = 0;
-    const bool probe = class_probing() && len >= ((size_t)1 << 30);   // blocks of 1 GiB and more: the candidates cost ~50 ms once
-                                                                       // (a streaming driver's chunk plans are smaller and skip this)
-    while (n < (probe ? NC : 1)) {
-        if (dev_alloc(p, &cand[n], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
-        t[n++] = -1.f;
-    }
-    if (n == 0) return nullptr;
-    int pick = 0;
-    bool opposite = false;
-    float tmax = -1.f;
-    if (probe && n > 1) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-            const unsigned grid = (unsigned)(len / 16 / 1024);
-            for (int rep = 0; rep < 6; ++rep)
-                for (int i = 0; i < n; ++i) {
-                    (void)hipEventRecord(e0, p->stream);
-                    hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)p->work, (float4*)cand[i], (int64_t)grid * 1024);
-                    (void)hipEventRecord(e1, p->stream);
-                    float ms = 0.f;
-                    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && (t[i] < 0 || ms < t[i]))
-                        t[i] = ms;
-                }
-        }
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
+    constexpr int kCandCap = 16;
+    void* cand[kCandCap] = {};
+    int n = 0, pick = 0, kMaxCand = kCandCap;
+    {   // never hold more than a quarter of the free memory
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) kMaxCand = (int)std::max<size_t>(1, std::min<size_t>(kCandCap, mfree / 4 / std::max<size_t>(bytes, 1)));
         (void)hipGetLastError();
-        for (int i = 0; i < n; ++i) {
-            if (t[i] > 0 && (t[pick] < 0 || t[i] < t[pick])) pick = i;
-            if (t[i] > tmax) tmax = t[i];
-        }
-        opposite = t[pick] > 0 && t[pick] < 0.975f * tmax;
     }
-    // (A second round of candidates behind a spacer allocation of a quarter of the free memory was tried for the processes
-    //  whose six candidates share one class: the 60-GiB hipMalloc alone takes 1.9 s -- not worth 4 %.)
+    const bool probe = class_probing() && len >= ((size_t)1 << 30) && kMaxCand > 1;
+    static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;
+    if (dev_alloc(p, &cand[0], bytes) != PBH_OK) { (void)hipGetLastError(); return nullptr; }
+    n = 1;
+    bool opposite = false;
+    float t_same = -1.f, t_diff = -1.f;
+    void* ref = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (probe && hipMalloc(&ref, 2 * len) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        if (out == in || out_bytes < ((size_t)1 << 30)) out = nullptr;   // detect tails and short crops: too small to matter / to time
+        const size_t len_out = out ? std::min(len, out_bytes & ~(size_t)16383) : 0;
+        auto copy_ms = [&](const void* a, void* b, size_t l) -> float {   // fastest of two after a warm-up copy
+            const unsigned grid = (unsigned)(l / 16 / 1024);
+            float best = -1.f;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0, p->stream);
+                hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)a, (float4*)b, (int64_t)grid * 1024);
+                (void)hipEventRecord(e1, p->stream);
+                float ms = 0.f;
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+                if (rep > 0 && (best < 0 || ms < best)) best = ms;
+            }
+            return best;
+        };
+        int best_score = -1;
+        float best_sum = 0.f;
+        while (true) {
+            void* c = cand[n - 1];
+            // the slow time, taken next to every candidate's copies (the part warms up while this runs)
+            const float ts = copy_ms(ref, (char*)ref + len, len);
+            const float tw = copy_ms(p->work, c, len);
+            const float tx = in ? copy_ms(in, c, len) : -1.f;
+            const float ty = out ? copy_ms(out, c, len_out) : -1.f;
+            if (ts <= 0 || tw <= 0) break;
+            const float ts_out = ts * (float)((double)len_out / (double)len);
+            const bool fw = tw < (1.f - 1.25f * kClassGap) * ts, fx = !in || (tx > 0 && tx < (1.f - 1.25f * kClassGap) * ts),
+                       fy = !out || (ty > 0 && ty < (1.f - 1.25f * kClassGap) * ts_out);
+            const int score = 4 * (int)fw + 2 * (int)fx + (int)fy;   // work <-> work2 first: two passes stream between them
+            const float sum = tw + (tx > 0 ? tx : 0.f) + (ty > 0 ? ty : 0.f);
+            if (trace)
+                fprintf(stderr, "[pbhip] work2 candidate %d at %p: same-class copy %.4f ms; from work %.4f%s, from the input %.4f%s, from the output %.4f%s\n",
+                        n, c, ts, tw, fw ? " (other class)" : "", tx, in && fx ? " (other class)" : "", ty, out && fy ? " (other class)" : "");
+            if (score > best_score || (score == best_score && sum < best_sum)) {
+                best_score = score; best_sum = sum; pick = n - 1;
+                opposite = fw; t_same = ts; t_diff = tw;
+            }
+            if ((fw && fx && fy) || n == kMaxCand) break;
+            if (dev_alloc(p, &cand[n], bytes) != PBH_OK) { (void)hipGetLastError(); break; }
+            ++n;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (ref) (void)hipFree(ref);
+    (void)hipGetLastError();
     for (int i = 0; i < n; ++i)
         if (i != pick) { (void)hipFree(cand[i]); p->owned_bytes -= (int64_t)bytes; }
     p->work2 = (cf*)cand[pick];
     if (opposite) {
-        p->cls_t_same = tmax;
-        p->cls_t_diff = t[pick];
+        p->cls_t_same = t_same;
+        p->cls_t_diff = t_diff;
         p->cls_len = std::min<size_t>(len, (size_t)1 << 30);
     }
-    static const bool trace = getenv("PBH_TRACE_ALLOC") != nullptr;
-    if (trace) {
-        fprintf(stderr, "[pbhip] work2: candidate %d of %d; copies work -> candidate:", pick + 1, n);
-        for (int i = 0; i < n; ++i) fprintf(stderr, " %.4f", t[i]);
-        fprintf(stderr, " ms%s\n", opposite ? "" : " (no two groups)");
-    }
+    if (trace) fprintf(stderr, "[pbhip] work2: candidate %d of %d%s\n", pick + 1, n, probe ? (opposite ? "" : " (none of another class than work)") : " (no probing)");
     return p->work2;
 }
+static cf* ensure_work2(pbh_plan* p) { return ensure_work2(p, nullptr, nullptr, 0); }
 // class of a caller's buffer relative to the plan's work buffer: 0 = the same, 1 = the other, -1 = unknown (small buffers,
 // plans without an opposite-class pair, undecided probes).  The probe copies from `ptr` into work and into work2 (scratch
 // between calls), alternating; whichever is faster is the buffer of the other class.  Cached per (pointer, size).
@@ -904,6 +929,7 @@ static cf* ensure_work2(pbh_plan* p) {
     }
     return p->work2;
 }
+static cf* ensure_work2(pbh_plan* p, const void*, const void*, size_t) { return ensure_work2(p); }
 #endif
 
 // true when the detect tail can be fused (planar work buffer holds the full dedispersed series)
@@ -1341,7 +1367,7 @@ std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tai
 #ifndef PBH_F64
         if (fd4_ok(p) && !in_sm && !out_sm && !unsplit && !fuse_radix && !io.mix_ft && io.in_valid < 0 && !depth_mode() && !oop_mode() &&
             colp_mode() != 0)
-            fdB = ensure_work2(p);
+            fdB = ensure_work2(p, in, tail.out ? nullptr : out, p->stop > p->start ? sizeof(cf) * (size_t)S * (size_t)(p->stop - p->start) : 0);
 #endif
         if (fdB) {
         } else if (fuse_radix) {
@@ -2307,7 +2333,7 @@ int pbh_plan_buffer_class(pbh_plan* p, const void* dev_ptr, int64_t bytes, int* 
     *cls = -1;
 #ifndef PBH_F64
     HIPCHECK(hipSetDevice(p->device));
-    if (fd4_ok(p) && !p->work2) (void)ensure_work2(p);
+    if (fd4_ok(p) && !p->work2) (void)ensure_work2(p, bytes >= (int64_t)(sizeof(cf) * (size_t)p->S * (size_t)p->N) ? dev_ptr : nullptr, nullptr, 0);
     if (dev_ptr && bytes > 0) *cls = buffer_class(p, dev_ptr, (size_t)bytes);
 #else
     (void)dev_ptr;
