@@ -101,12 +101,12 @@ int pbh_plan_set_stream(pbh_plan* plan, void* hip_stream);
 int pbh_plan_set_variant(pbh_plan* plan, int variant);
 int pbh_plan_info(const pbh_plan* plan, pbh_plan_info_t* info);
 
-/* Placement aid (no reference counterpart; measurement-driven).  On MI355X every large device allocation belongs
- * to one of two "classes", and a pass that streams from one allocation into another is ~5 % faster when their classes
- * differ.  The plan keeps its two work buffers of opposite class and orders its passes around the caller's buffers; a host
- * that can choose WHERE its input and output live (bench.py does) asks here: *cls = 0 when the `bytes` at `dev_ptr` are of
- * the class of the plan's first work buffer, 1 when of the other, -1 when that cannot be told (buffers under 1 GiB, plans
- * that run in one work buffer).  The fastest arrangement gives input and output the SAME class.  Costs one timed 1-GiB device
+/* Placement query (no reference counterpart; measurement-driven).  On MI355X every large device allocation belongs
+ * to a "class" (runs of 8 / 32 GiB of the allocator's heap), and a pass that streams from one allocation into another of the SAME
+ * class is ~5 % slower.  On its first call a plan looks for a second work buffer of another class than its first one, the
+ * caller's input and the caller's output (reading them only), so nothing needs to be done by the host; this entry point merely
+ * reports: *cls = 0 when the `bytes` at `dev_ptr` are of the class of the plan's first work buffer, 1 when of that of the second,
+ * -1 otherwise or when it cannot be told (buffers under 1 GiB, plans that run in one work buffer).  Costs one timed 1-GiB device
  * copy (reads dev_ptr, writes plan scratch) the first time a pointer is seen; synchronises the plan's stream.             */
 int pbh_plan_buffer_class(pbh_plan* plan, const void* dev_ptr, int64_t bytes, int* cls);
 

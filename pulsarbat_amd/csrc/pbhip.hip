@@ -839,6 +839,14 @@ static cf* ensure_work2(pbh_plan* p, const void* in, const void* out, size_t out
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (probe && hipMalloc(&ref, 2 * len) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         if (out == in || out_bytes < ((size_t)1 << 30)) out = nullptr;   // detect tails and short crops: too small to matter / to time
+        auto local = [&](const void* q) {   // only this device's own memory is worth (and safe) to time: not a peer's mapping, not host memory
+            hipPointerAttribute_t at;
+            const bool ok = hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == p->device;
+            (void)hipGetLastError();
+            return ok;
+        };
+        if (in && !local(in)) in = nullptr;
+        if (out && !local(out)) out = nullptr;
         const size_t len_out = out ? std::min(len, out_bytes & ~(size_t)16383) : 0;
         auto copy_ms = [&](const void* a, void* b, size_t l) -> float {   // fastest of two after a warm-up copy
             const unsigned grid = (unsigned)(l / 16 / 1024);
@@ -1367,7 +1375,8 @@ std::vector<Step> build_steps(pbh_plan* p, const cf* in, cf* out, DetectTail tai
 #ifndef PBH_F64
         if (fd4_ok(p) && !in_sm && !out_sm && !unsplit && !fuse_radix && !io.mix_ft && io.in_valid < 0 && !depth_mode() && !oop_mode() &&
             colp_mode() != 0)
-            fdB = ensure_work2(p, in, tail.out ? nullptr : out, p->stop > p->start ? sizeof(cf) * (size_t)S * (size_t)(p->stop - p->start) : 0);
+            fdB = ensure_work2(p, in, tail.out || !io.part_ptr.empty() ? nullptr : out,   // (a split output: `out` is its first part only)
+                               p->stop > p->start ? sizeof(cf) * (size_t)S * (size_t)(p->stop - p->start) : 0);
 #endif
         if (fdB) {
         } else if (fuse_radix) {

@@ -74,3 +74,47 @@ def test_not_taken_where_the_geometry_does_not_fit():
     assert names[0] == "k_deinterleave"
     _, got, names, _ = _run(20, 5, 2, 10.0, 5)          # S = 10
     assert names[0] == "k_deinterleave"
+
+
+_SEARCH = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from oracle import dedisp_oracle as orc
+from pulsarbat_amd import _hip
+from pulsarbat_amd.device import DeviceArray
+n, nchan, npol, dm, sr, fc = 1 << 23, 8, 2, 30.0, 1e6, 1e9
+x = orc.synthetic_block((n, nchan, npol), 11)
+start, stop = orc.crop_bounds(dm, n, nchan, sr, fc, fc)
+freqs = fc + sr * (np.arange(nchan) + 0.5 - nchan / 2)
+with _hip.Plan(n, nchan, npol, start, stop) as plan:
+    plan.chirp_generate(dm / 2.41e-4 * 1e12, 1 / sr, freqs, fc)
+    xd = DeviceArray.from_host(x)
+    y = np.asarray(plan.dedisperse(xd))
+    y2 = np.asarray(plan.dedisperse(xd))
+    assert np.array_equal(y, y2)
+    cls = plan.buffer_class(xd)
+    assert cls in (-1, 0, 1), cls
+    assert np.array_equal(np.asarray(xd), x)          # the search only reads the caller's arrays
+print("digest", hashlib.sha256(y.tobytes()).hexdigest())
+"""
+
+
+def test_second_work_buffer_search():
+    """The first call of a plan with blocks of 1 GiB and more looks for a second work buffer of another allocation class than
+    the first one, the input and the output (csrc/pbhip.hip: ensure_work2; DESIGN.md 6d d).  Placement is a speed matter only:
+    the result is bit-identical with the search switched off, the caller's input is left as it was, the trace names the pick."""
+    import subprocess
+    import sys
+    outs = {}
+    for cls in ("1", "0"):
+        env = dict(os.environ, PBH_CLASS=cls, PBH_TRACE_ALLOC="1")
+        r = subprocess.run([sys.executable, "-c", _SEARCH.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[cls] = ([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0], r.stderr)
+    assert outs["1"][0] == outs["0"][0]
+    picked = [ln for ln in outs["1"][1].splitlines() if "work2: candidate" in ln]
+    assert len(picked) == 1 and "no probing" not in picked[0], outs["1"][1][-1500:]
+    timed = [ln for ln in outs["1"][1].splitlines() if "work2 candidate" in ln]
+    assert 1 <= len(timed) <= 16 and all("from the input" in ln for ln in timed)
+    assert "(no probing)" in [ln for ln in outs["0"][1].splitlines() if "work2: candidate" in ln][0]
