@@ -765,13 +765,14 @@ static int oop_mode() {
 }
 #ifndef PBH_F64
 // ---- allocation classes ---------------------------------------------------------------------------------------------------
-// Measured on MI355X (tools/micro/bufprobe.hip, profiles/r04_bufprobe.txt): every large hipMalloc allocation belongs to one of
-// two classes; a copy between allocations of the SAME class (or inside one allocation) takes 0.755 ms per 2 GiB, between
-// allocations of DIFFERENT class 0.72 ms, whatever the offsets inside them -- and the passes of this library follow: the
-// de-interleave pass 0.80 / 0.75 ms, the column passes out of place 0.86 / 0.82 and 0.756 / 0.72, the direct forward pass
-// 1.42 / 1.33.  That is the 2.5 % per-process spread of round 3: which classes the process's buffers happened to get.  The
-// class of an allocation cannot be asked for, but a pair can be probed: one timed copy between them against a copy inside the
-// plan's own work buffer (same class by definition).
+// Measured on MI355X (tools/micro/bufprobe.hip, classprobe2.hip; profiles/r04_bufprobe.txt, r04_classprobe2_blocks.txt): every
+// large hipMalloc allocation belongs to a class (at least three exist; runs of 8 / 32 GiB of the allocator's heap share one); a
+// copy between allocations of the SAME class (or inside one allocation) takes 0.755 ms per 2 GiB, between allocations of
+// DIFFERENT class 0.72 ms, whatever the offsets inside them -- and the passes of this library follow: the de-interleave pass
+// 0.80 / 0.75 ms, the column passes out of place 0.86 / 0.82 and 0.756 / 0.72, the direct forward pass 1.25 / 1.18.  That is
+// the 2.5 % per-process spread of round 3: which classes the process's buffers happened to get.  The class of an allocation
+// cannot be asked for, but a pair can be probed: one timed copy between them against a copy inside one allocation (same class
+// by definition).
 // Copies of `bytes` from a to b1 and from a to b2, alternating, REPS times each: the fastest of each (the first pair warms the
 // TLBs and does not count).  The two times come from the same moments of the same chip, which is what makes a 4-5 %
 // difference readable (single timings of a 1-GiB copy scatter by 2 %).
