@@ -816,13 +816,13 @@ constexpr float kClassGap = 0.02f;   // relative difference of the two copies be
 // definition, inside one allocation.  So: a 4-GiB reference allocation gives the slow time (first half -> second half), and
 // candidates are allocated one after the other (all held, so that the allocator walks on through its heap) until one copies fast
 // from `work`, from the caller's input and from the caller's output (read only: nothing of the caller's is written); at most
-// 16 of them and never more than a quarter of the free memory (32 GiB held for ~0.2 s in the worst case at 2 GiB per block).  With PBH_CLASS=0, or
+// 24 of them and never more than a quarter of the free memory (48 GiB held for ~0.2 s in the worst case at 2 GiB per block).  With PBH_CLASS=0, or
 // for blocks under 1 GiB (a streaming driver's chunk plans), the first allocation is taken as it comes.
 static cf* ensure_work2(pbh_plan* p, const void* in, const void* out, size_t out_bytes) {
     if (p->work2 || !p->work) return p->work2;
     const size_t bytes = sizeof(cf) * (size_t)p->S * (size_t)p->N;
     const size_t len = bytes & ~(size_t)16383;
-    constexpr int kCandCap = 16;
+    constexpr int kCandCap = 24;   // runs of one class are up to 16 blocks of 2 GiB long (r04_classprobe2_blocks.txt)
     void* cand[kCandCap] = {};
     int n = 0, pick = 0, kMaxCand = kCandCap;
     {   // never hold more than a quarter of the free memory
@@ -849,10 +849,10 @@ static cf* ensure_work2(pbh_plan* p, const void* in, const void* out, size_t out
         if (in && !local(in)) in = nullptr;
         if (out && !local(out)) out = nullptr;
         const size_t len_out = out ? std::min(len, out_bytes & ~(size_t)16383) : 0;
-        auto copy_ms = [&](const void* a, void* b, size_t l) -> float {   // fastest of two after a warm-up copy
+        auto copy_ms = [&](const void* a, void* b, size_t l) -> float {   // fastest of three after a warm-up copy
             const unsigned grid = (unsigned)(l / 16 / 1024);
             float best = -1.f;
-            for (int rep = 0; rep < 3; ++rep) {
+            for (int rep = 0; rep < 4; ++rep) {
                 (void)hipEventRecord(e0, p->stream);
                 hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, p->stream, (const float4*)a, (float4*)b, (int64_t)grid * 1024);
                 (void)hipEventRecord(e1, p->stream);
@@ -864,17 +864,36 @@ static cf* ensure_work2(pbh_plan* p, const void* in, const void* out, size_t out
         };
         int best_score = -1;
         float best_sum = 0.f;
+        // `slow` = the fastest same-class copy seen so far (the reference's, taken again next to every second candidate: the part
+        // warms up while this runs).  The two groups lie 4-5 % apart and scatter by 1-2 % each: a pair counts as of two classes
+        // when its copy beats 0.984 x slow twice.
+        float slow = -1.f;
+        auto note_slow = [&](float t) { if (t > 0 && (slow < 0 || t < slow)) slow = t; };
+        auto fast = [&](const void* a, void* b, size_t l, float* t) {
+            const float scale = (float)((double)l / (double)len);
+            *t = copy_ms(a, b, l);
+            if (*t <= 0 || *t >= 0.984f * slow * scale) return false;
+            const float again = copy_ms(a, b, l);
+            if (again > *t) *t = again;
+            return again > 0 && again < 0.984f * slow * scale;
+        };
+        note_slow(copy_ms(ref, (char*)ref + len, len));
+        // is `work` itself of another class than the caller's arrays?  Then it can take the Q4 intermediate (input -> work -> work2
+        // -> work -> output) and any candidate that differs from work will do; else the candidate has to differ from all three
+        float twx = -1.f, twy = -1.f;
+        const bool work_free = slow > 0 && (!in || fast(in, p->work, len, &twx)) && (!out || fast(out, p->work, len_out, &twy));
+        if (trace) fprintf(stderr, "[pbhip] work %p: same-class copy %.4f ms; from the input %.4f, from the output %.4f%s\n", (void*)p->work, slow, twx, twy,
+                           work_free ? " (of another class than both)" : "");
         while (true) {
             void* c = cand[n - 1];
-            // the slow time, taken next to every candidate's copies (the part warms up while this runs)
-            const float ts = copy_ms(ref, (char*)ref + len, len);
-            const float tw = copy_ms(p->work, c, len);
-            const float tx = in ? copy_ms(in, c, len) : -1.f;
-            const float ty = out ? copy_ms(out, c, len_out) : -1.f;
-            if (ts <= 0 || tw <= 0) break;
-            const float ts_out = ts * (float)((double)len_out / (double)len);
-            const bool fw = tw < (1.f - 1.25f * kClassGap) * ts, fx = !in || (tx > 0 && tx < (1.f - 1.25f * kClassGap) * ts),
-                       fy = !out || (ty > 0 && ty < (1.f - 1.25f * kClassGap) * ts_out);
+            if ((n - 1) % 2 == 0) note_slow(copy_ms(ref, (char*)ref + len, len));
+            if (slow <= 0) break;
+            float tw = -1.f, tx = -1.f, ty = -1.f;
+            const bool fw = fast(p->work, c, len, &tw);
+            if (tw <= 0) break;
+            // the caller's arrays only for candidates that differ from work (a run of one class is walked through at ~7 ms per block)
+            const bool fx = fw && (work_free || !in || fast(in, c, len, &tx)), fy = fw && (work_free || !out || fast(out, c, len_out, &ty));
+            const float ts = slow;
             const int score = 4 * (int)fw + 2 * (int)fx + (int)fy;   // work <-> work2 first: two passes stream between them
             const float sum = tw + (tx > 0 ? tx : 0.f) + (ty > 0 ? ty : 0.f);
             if (trace)
