@@ -397,9 +397,10 @@ int pbh_real_to_complex(int device, void* hip_stream, const void* in_dev, void* 
 
 /* Device-to-device streaming copy of `bytes` (float4 per lane): the achievable-HBM reference number. */
 int pbh_copy_bench(int device, int64_t bytes, int iters, float* ms_mean);
-/* The same yardstick with a mode: 0 = copy between two buffers of `bytes` (= pbh_copy_bench), 1 = read-modify-write of ONE
- * buffer in place -- the ceiling of the three middle passes of pbh_dedisperse, which update the planar work buffer where it
- * stands (no reference counterpart: measurement support for bench.py's path_roofline).                                  */
+/* The same yardstick with a mode: 0 = copy between two buffers of `bytes` (= pbh_copy_bench; for 1 GiB and more the destination
+ * is the fastest of up to twelve allocations: a copy between two allocations of one class is 4-5 % slower, DESIGN.md 6d d),
+ * 1 = read-modify-write of ONE buffer in place -- the ceiling of the three middle passes of the five-pass schedule, which update
+ * the planar work buffer where it stands (no reference counterpart: measurement support for bench.py's path_roofline).      */
 int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_mean);
 
 #ifdef __cplusplus

@@ -59,7 +59,11 @@ int pbh_plan_profile(pbh_plan* p, const void* in_dev, void* out_dev, int iters, 
 
 #ifndef PBH_F64
 // mode 0: copy a -> b (two buffers of `bytes`); mode 1: read-modify-write of ONE buffer in place (what the three middle
-// passes do to the planar work buffer).  Mean milliseconds per launch over `iters` launches, HIP events on the null stream.
+// passes of the five-pass schedule do to the planar work buffer).  Mean milliseconds per launch over `iters` launches, HIP
+// events on the null stream.  A copy between two allocations of one class is 4-5 % slower than between two classes (DESIGN.md
+// 6d d), and consecutive allocations usually share theirs: for buffers of 1 GiB and more mode 0 therefore walks through up to
+// twelve destination candidates (all held, two timed copies each) and measures with the fastest -- the ceiling is what a copy
+// CAN do on this part, as the passes of the four-pass schedule are arranged to.
 int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_mean) {
     if (!ms_mean || bytes < 16 || iters <= 0 || mode < 0 || mode > 1) return fail(PBH_ERR_INVALID, "bad argument");
     HIPCHECK(hipSetDevice(device));
@@ -73,6 +77,41 @@ int pbh_stream_bench(int device, int64_t bytes, int iters, int mode, float* ms_m
     if (rc == PBH_OK) {
         const int64_t n = bytes / 16;
         const unsigned grid = (unsigned)((n + 1023) / 1024);
+        if (mode == 0 && bytes >= ((int64_t)1 << 30) && hipMemset(a, 0, (size_t)bytes) == hipSuccess) {
+            constexpr int NC = 12;
+            void* cand[NC] = {b};
+            float t[NC];
+            int nc = 1, best = 0;
+            float tmax = 0.f;
+            hipEvent_t c0 = nullptr, c1 = nullptr;
+            if (hipEventCreate(&c0) == hipSuccess && hipEventCreate(&c1) == hipSuccess) {
+                size_t mfree = 0, mtotal = 0;
+                (void)hipMemGetInfo(&mfree, &mtotal);
+                while (true) {
+                    float tb = -1.f;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        (void)hipEventRecord(c0, 0);
+                        hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)cand[nc - 1], n);
+                        (void)hipEventRecord(c1, 0);
+                        float x = 0.f;
+                        if (hipEventSynchronize(c1) == hipSuccess && hipEventElapsedTime(&x, c0, c1) == hipSuccess && rep > 0 && (tb < 0 || x < tb)) tb = x;
+                    }
+                    t[nc - 1] = tb;
+                    if (tb > tmax) tmax = tb;
+                    if (tb > 0 && tb < t[best]) best = nc - 1;
+                    // two groups seen and this one in the fast one, or out of candidates / memory
+                    if ((t[best] > 0 && t[best] < 0.97f * tmax) || nc == NC || (size_t)bytes * (size_t)(nc + 1) > mfree / 4) break;
+                    if (hipMalloc(&cand[nc], (size_t)bytes) != hipSuccess) break;
+                    ++nc;
+                }
+            }
+            if (c0) (void)hipEventDestroy(c0);
+            if (c1) (void)hipEventDestroy(c1);
+            (void)hipGetLastError();
+            for (int i = 0; i < nc; ++i)
+                if (i != best) (void)hipFree(cand[i]);
+            b = cand[best];
+        }
         auto launch = [&] {
             if (mode == 0) hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n);
             else hipLaunchKernelGGL(k_copy<true>, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)a, n);
