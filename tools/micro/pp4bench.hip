@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512) void k_fdq(const float2* __restrict__ in, floa
 // SUB = log2 of the columns of a sub-block: the same pieces with the rows of a tile 2^SUB x 128 B apart instead of 2 MiB (sub-blocks of
 // (1024, 2^SUB, 16)): is the cost of a
 // partial-line load the LINE, or the 2-MiB page each of its rows lives in?
-template <int MODE, int LW, int SW, int SUB = 0>
+template <int MODE, int LW, int SW, int SUB = 0, int WC = 0>   // WC (8-byte stores): 1 = a tile's outputs as ONE contiguous 128-KiB block, 2 = rows of a tile 1 KiB apart in 8-row chunks
 __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, float2* __restrict__ out, float* sink) {
     const int tid = threadIdx.x;
     const uint32_t b = blockIdx.x, xg = b & 7u, li = b >> 3;
@@ -359,7 +359,9 @@ __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, flo
     else          { const int ser = tid & 3, c = (tid >> 2) & 3, t = tid >> 4; voff_in = ((t * N2E + c) * S + ser) * 8; }
     if (SW == 16) { const int cp = tid & 1, ser = (tid >> 1) & 3, k = tid >> 3; voff_out = (k * 4 * N2 + ser * 4 + cp * 2) * 8; }
     else          { const int c = tid & 3, ser = (tid >> 2) & 3, k = tid >> 4; voff_out = (k * 4 * N2 + ser * 4 + c) * 8; }
-    constexpr uint32_t SIN = (uint32_t)(1024 / NLD) * N2E * S * 8, SOUT = (uint32_t)(1024 / NST) * 4 * N2 * 8;
+    if (WC == 1) voff_out = tid * 8;
+    if (WC == 2) { const int c = tid & 3, ser = (tid >> 2) & 3, k = tid >> 4; voff_out = ((k >> 3) * 4 * N2 * 8 + (k & 7) * 16 + ser * 4 + c) * 8; }   // [k1/8][n2/4][k1%8][16]
+    constexpr uint32_t SIN = (uint32_t)(1024 / NLD) * N2E * S * 8, SOUT = WC == 1 ? 4096u : (uint32_t)(1024 / NST) * 4 * N2 * 8;
     constexpr uint32_t in_span = (uint32_t)(((int64_t)(N1 - 1) * N2E * S + 3 * S + 4) * 8);
     constexpr uint32_t out_span = (uint32_t)(((int64_t)(N1 - 1) * 4 * N2 + 16) * 8);
     auto in_rsrc = [&](uint32_t k) {
@@ -371,6 +373,8 @@ __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, flo
     auto out_rsrc = [&](uint32_t k) {
         const uint32_t g = k * 64 + gang;
         if (g >= NG) return make_rsrc(out, 0);
+        if (WC == 1) return make_rsrc(out + ((int64_t)g * 4 + member) * 16384, 131072u);
+        if (WC == 2) return make_rsrc(out + ((int64_t)member * N1 * 4 * N2 + (int64_t)g * 128), out_span);
         return make_rsrc(out + ((int64_t)member * N1 * 4 * N2 + (int64_t)g * 16), out_span);
     };
     float v[64], nx[64];
@@ -778,6 +782,12 @@ int main(int argc, char** argv) {
             W(1, 16, 8, "fdqw 16-byte loads only", 1.0 * bytes)
             W(2, 8, 8, "fdqw  8-byte stores only", 1.0 * bytes)
             W(2, 8, 16, "fdqw 16-byte stores only", 1.0 * bytes)
+#define W2(WCm, M, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, 8, 8, 0, WCm>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
+            W2(1, 2, "stores only, tile = one contiguous 128-KiB block", 1.0 * bytes)
+            W2(2, 2, "stores only, 8-row chunks (1 KiB runs)", 1.0 * bytes)
+            W2(1, 0, "loads + stores, tile out = contiguous block", two)
+            W2(2, 0, "loads + stores, 8-row chunks", two)
+#undef W2
 #define W1(SB, M, L, St, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, L, St, SB>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
             W1(6, 1, 8, 8, "rows   8 KiB apart: 8-byte loads only", 1.0 * bytes)
             W1(8, 1, 8, 8, "rows  32 KiB apart: 8-byte loads only", 1.0 * bytes)
