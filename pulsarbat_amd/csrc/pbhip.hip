@@ -458,13 +458,15 @@ static int launch_rowq(const RowqParams& prm, hipStream_t st) {
 #endif
     return launch_tile_kernel(k_rowq16<PBH_R, 10>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<true>() + 16);
 }
-// geometry the four-pass schedule covers: quads of series, one row tile per row, 1024-row column tiles whose 2-GiB span of
-// the caller's block fits a buffer descriptor's 32-bit offsets
+// geometry the four-pass schedule covers: quads of series (up to 16 of them), one row tile per row, column tiles of up to
+// 1024 rows whose span of the caller's block fits a buffer descriptor's 32-bit offsets
 static bool fd4_ok(const pbh_plan* p) {
     if (fd4_mode() == 0 || !p->has_phase || !row_phase_enabled() || !p->phase16) return false;
-    if (p->P != 1 || p->N2 != kTilePoints || p->N1 < 64 || p->N1 > 1024 || !is_pow2(p->N1) || p->S % 4 != 0 || p->S < 4 || p->S > 16) return false;
-    const int64_t span = (((int64_t)(p->N1 - 1) * p->N2 + 3) * p->S + 4) * (int64_t)sizeof(cf);
-    return span < (1LL << 32) && (int64_t)31 * (p->N1 / PBH_R) * p->N2 * p->S * (int64_t)sizeof(cf) < (1LL << 31);
+    if (p->P != 1 || p->N2 != kTilePoints || p->N1 < 64 || p->N1 > 1024 || !is_pow2(p->N1) || p->S % 4 != 0 || p->S < 4 || p->S > 64) return false;
+    // a tile's rows reach over the whole block: its span and the last row's offset have to fit the 32 unsigned bits of a buffer
+    // descriptor's record count and of voffset + soffset (2^24 samples: up to 32 series; 2^22: up to 64)
+    const int64_t span = (((int64_t)(p->N1 - 1) * p->N2 + (kTilePoints / p->N1) / 4 - 1) * p->S + 4) * (int64_t)sizeof(cf);
+    return span < (1LL << 32) && ((int64_t)(p->N1 - 1) * p->N2 + kTilePoints / p->N1) * p->S * (int64_t)sizeof(cf) < (1LL << 32);
 }
 #endif
 

@@ -40,7 +40,9 @@ def _digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-CASES = [(20, 8, 2, 30.0), (20, 2, 2, 10.0), (20, 4, 1, 30.0), (20, 6, 2, 50.0), (21, 4, 2, 30.0), (22, 8, 2, 60.0), (23, 2, 2, 100.0)]
+CASES = [(20, 8, 2, 30.0), (20, 2, 2, 10.0), (20, 4, 1, 30.0), (20, 6, 2, 50.0), (21, 4, 2, 30.0), (22, 8, 2, 60.0), (23, 2, 2, 100.0),
+         # more than one 128-byte line of series per sample: gangs of 5, 6, 8 and 16 quads
+         (20, 10, 2, 30.0), (20, 12, 2, 30.0), (20, 16, 2, 30.0), (20, 32, 2, 30.0), (21, 32, 1, 20.0)]
 
 
 @pytest.mark.parametrize("log2n,nchan,npol,dm", CASES)
