@@ -1,6 +1,6 @@
 """Randomised check of the four-pass schedule (csrc/fd4_kernels.hpp) with guards: the input is a view into a larger device
 buffer of NaNs (any read outside the block poisons the result), the output a view into a buffer of sentinels (any write outside
-it shows).  Quad-series blocks S in {4, 8, 12, 16}, 2^20 ... 2^24 samples (column tiles of 64 ... 1024 rows), random crops,
+it shows).  Quad-series blocks S in {4, 8, ..., 64}, 2^20 ... 2^24 samples (column tiles of 64 ... 1024 rows), random crops,
 channel / pol splits and view offsets; every case against the five-pass schedule on the same input (PBH_FD4=0; equal to the
 last bits) and, up to 2^21 samples, against the oracle.
 usage: fuzz_fd4.py [seconds] [seed]"""
@@ -26,11 +26,11 @@ SR, FC = 1e6, 1e9
 print(f"seed {seed}", flush=True)
 while time.time() < t_end:
     log2n = int(rng.integers(20, 25))
-    S = int(rng.choice([4, 8, 12, 16]))
+    S = int(rng.choice([4, 8, 12, 16, 16, 20, 24, 28, 32, 36, 40, 48, 64]))
     n = 1 << log2n
     if n * S > (1 << 27):
         continue
-    splits = [(c, S // c) for c in (1, 2, 3, 4, 6, 8, 12, 16) if S % c == 0 and S // c in (1, 2, 4)]
+    splits = [(c, S // c) for c in range(1, S + 1) if S % c == 0 and S // c in (1, 2, 4)]
     nchan, npol = splits[int(rng.integers(0, len(splits)))]
     dm = float(rng.uniform(0.0, 60.0)) * (n / (1 << 24)) * (8.0 / max(nchan, 1)) + float(rng.uniform(0, 0.2))
     start, stop = orc.crop_bounds(dm, n, nchan, SR, FC, FC)
