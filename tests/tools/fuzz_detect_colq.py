@@ -56,10 +56,12 @@ while time.time() < t_end:
     got = np.asarray(got).reshape(want.shape)
     zs = type(z).like(z, z.data.to_series_major())
     got_s, _ = pb.dedisperse_detect(zs, pb.DM(dm), ref_freq=rf, mode=mode, nscrunch=ns)
-    err = float(np.max(np.abs(got - want) / scale))
-    # (one or two series run the 3-pass variant from a sample-major block and detect in a pass of their own: the two results
-    #  are then sums in different orders, not the same bits)
-    same = float(np.max(np.abs(np.asarray(got_s).reshape(want.shape) - want) / scale)) < 3e-5
+    # bound as in tests/_detect_check.py: every output against its own Stokes I from 16 summed samples on, against the MEAN power
+    # below that (a single |z|^2 can be arbitrarily small, and the sample-major block runs the four-pass schedule since round 4:
+    # its voltages agree with the series-major route's to 2e-7 of the rms, not to the last bit)
+    ref_scale = scale if ns >= 16 else np.full_like(scale, float(np.mean(scale)))
+    err = float(np.max(np.abs(got - want) / ref_scale))
+    same = float(np.max(np.abs(np.asarray(got_s).reshape(want.shape) - want) / ref_scale)) < 3e-5
     residues.add(start % 16)
     cases += 1
     if not (err < 3e-5 and same):
