@@ -62,7 +62,12 @@ struct ColfdParams {
 //       between the stores: 1.22; every second tick: 1.18; no loads inside the transform: 1.27
 //   0 = k_colq's pacing: stores deferred into the next transform, two (store, load) pairs per tick -- 1.34 ms
 //   1 = one deferred pair per tick, the last eight between the twiddle products -- 1.38 ms
-template <int M, int R, int SP = 2>
+// TWR: 1 (default) = the inter-pass twiddle's base and step of the NEXT tile by recurrence -- its column is a fixed distance
+//   (gangs x C) from this tile's, so base' = base x W_N^{dn2 tau}, step' = step x W_N^{dn2 MR} (float64, at most N2 / C / gangs
+//   products in a row: 1e-14) -- instead of four table reads per tile, two of which are 16-line gathers on the address path this
+//   kernel is bound by: 1.186 -> 1.165 ms at config 2, 25 VGPRs fewer; 0 = the tables for every tile (k_colq's way, whose tile
+//   order is not static)
+template <int M, int R, int SP = 2, int TWR = 1>
 __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     constexpr int F = kTilePoints / M;   // columns of a tile: 4 series x C columns n2
     constexpr int C = F / 4;
@@ -112,6 +117,12 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     rsrc_t rdo = make_rsrc(p.q4, 0);   // where the outputs waiting in `out` go (none yet)
     double2 zbh, zbl, zsh, zsl;
     load_tables((int)g * C + c, zbh, zbl, zsh, zsl);
+    double2 zb_next = zmul(zbh, zbl), zs_next = zmul(zsh, zsl), dzb = make_double2(1.0, 0.0), dzs = make_double2(1.0, 0.0);
+    if constexpr (TWR != 0) {
+        const int64_t dn2 = (int64_t)gg.ngang * C;
+        dzb = big_tw(p.tw, dn2 * tau);
+        dzs = big_tw(p.tw, dn2 * MR);
+    }
     cf v[R], out[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -121,7 +132,8 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
 
     while (true) {
         launder_all(w, std::make_integer_sequence<int, tw_seeds_or1(M, R)>{});
-        const double2 zb = zmul(zbh, zbl), zs = zmul(zsh, zsl);
+        const double2 zb = TWR ? zb_next : zmul(zbh, zbl), zs = TWR ? zs_next : zmul(zsh, zsl);
+        if constexpr (TWR != 0) { zb_next = zmul(zb, dzb); zs_next = zmul(zs, dzs); }
         const uint32_t gn = g + gg.ngang;
         const bool more = gn < ngrp;
         const rsrc_t rd2 = in_rsrc(gn);            // tile whose samples are requested during this iteration
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
                 if (cnt < R - LEFT) pump(1);
         }
         // tables of the next tile: after every request above
-        if (more && SP != 1) load_tables((int)gn * C + c, zbh, zbl, zsh, zsl);
+        if (more && SP != 1 && TWR == 0) load_tables((int)gn * C + c, zbh, zbl, zsh, zsl);
         if constexpr (SP == 2) rdo = out_rsrc(g);
         double2 z = zb;
 #pragma unroll
