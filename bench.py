@@ -15,7 +15,8 @@ One "step" = one call of the product's sharded entry point,
 pulsarbat_amd.shard.coherent_dedispersion_sharded (FFT -> chirp -> IFFT -> crop on this rank's
 channels with the full band's crop; at N=1 the rank holds the whole band), on a block already
 resident in HBM, output left resident and sharded.  Plan and chirp are cached per geometry after the first call;
-chirp generation is timed separately (reported as chirp_ms).
+chirp generation is timed separately (reported as chirp_ms), and so is the plan's first call (plan_first_call_ms: one-time
+buffer placement, part of plan set-up).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu]
   N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -283,6 +284,13 @@ def main():
     plan.chirp_generate(coeff, 1.0 / sr, freqs, CENTER_HZ)
     torch.cuda.synchronize()
     chirp_ms = (time.perf_counter() - t0) * 1e3
+    # plan set-up ends with ONE priming call: a plan's first call looks for its second work buffer among fresh allocations and
+    # times its four buffer-role assignments (one-time, 0.05-0.3 s; DESIGN.md 6d d).  That belongs to plan creation, not to the
+    # W warm-up steps -- with --warmup 0 it would otherwise land in the timed region.
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    prime_ms = (time.perf_counter() - t0) * 1e3
     mark("plan + chirp ready")
 
     def barrier():
@@ -434,7 +442,7 @@ def main():
                        "nsample": nsample, "nchan_per_gpu": NCHAN_PER_GPU, "npol": NPOL,
                        "nchan_total": nchan_total, "crop": [start, stop], "variant": info["variant"],
                        "n1": info["n1"], "n2": info["n2"], "sharding": "channels across ranks, no collective"},
-            "roofline": roofline, "path_roofline": path, "chirp_ms": chirp_ms,
+            "roofline": roofline, "path_roofline": path, "chirp_ms": chirp_ms, "plan_first_call_ms": prime_ms,
             "ms_per_step_event_median": event_median_ms, "event_steps": ev_n,
             "step": "pulsarbat_amd.shard.coherent_dedispersion_sharded (cached plan + chirp), output left sharded",
         }
