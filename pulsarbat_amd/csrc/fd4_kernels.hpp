@@ -67,7 +67,9 @@ struct ColfdParams {
 //   products in a row: 1e-14) -- instead of four table reads per tile, two of which are 16-line gathers on the address path this
 //   kernel is bound by: 1.186 -> 1.165 ms at config 2, 25 VGPRs fewer; 0 = the tables for every tile (k_colq's way, whose tile
 //   order is not static)
-template <int M, int R, int SP = 2, int TWR = 1>
+// STAUX: cache policy of the Q4 stores: 2 = nt (default: the lines are not read again before 2 GiB of other traffic have passed;
+//   1.157 -> 1.135 ms at config 2; the same hint on the row pass's and the inverse column pass's stores moved nothing: r04_ab_colfd_pacing.txt)
+template <int M, int R, int SP = 2, int TWR = 1, int STAUX = 2>
 __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     constexpr int F = kTilePoints / M;   // columns of a tile: 4 series x C columns n2
     constexpr int C = F / 4;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
                 }
             }
             out[i] = cmul(v[i], make_cf((real)z.x, (real)z.y));
-            if constexpr (SP == 2) buf_store(rdo, voff_out, (int)(i * step_out), out[i]);
+            if constexpr (SP == 2) buf_store<STAUX>(rdo, voff_out, (int)(i * step_out), out[i]);
             z = zmul(z, zs);
         }
         if constexpr (SP == 1) {

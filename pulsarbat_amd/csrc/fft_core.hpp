@@ -529,10 +529,11 @@ __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
 // (`buffer_store_dwordx4 v[92:95], ..., s63 offen` then `v_fma_f64 v[94:95], ...`), stores stale data
 // in 4 of every 16 lanes.  The hazard recognizer only guards the no-soffset form.  Every complex128
 // store therefore carries its own wait states, and nothing is scheduled across them.
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     union { u32x4 u; cf c; } x;
     x.c = a;
-    __builtin_amdgcn_raw_buffer_store_b128(x.u, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(x.u, r, voff, soff, AUX);
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_nop 3");
     __builtin_amdgcn_sched_barrier(0);
@@ -543,24 +544,26 @@ __device__ __forceinline__ cf buf_load(rsrc_t r, int voff, int soff) {
     u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, PBH_LOAD_AUX);
     return make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
 }
+template <int AUX = PBH_STORE_AUX>   // cache policy bits: 1 sc0, 2 nt, 16 sc1
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, cf a) {
     u32x2 x;
     x.x = __float_as_uint(a.x);
     x.y = __float_as_uint(a.y);
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, PBH_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, AUX);
 }
 // Two complex64 values as ONE 16-byte store.  The same gfx950 hazard as the complex128 store above applies: met again in
 // round 4 in k_rowq16, where hipcc computed the last butterfly's sums into the registers of the previous store
 // (`buffer_store_dwordx4 v[70:73], v84, s[16:19], s44 offen` / `v_add_f32 v70, ...`): lanes 12-15 of every 16 stored the NEXT
 // pair's first value.  The wait states ride on every 16-byte store; tests/test_abi.py scans the built code object for the
 // pattern (tools/isa_hazards.py) so that a store added without them fails on the CPU box.
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_pair(rsrc_t r, int voff, int soff, cf a, cf b) {
     u32x4 x;
     x.x = __float_as_uint(a.x);
     x.y = __float_as_uint(a.y);
     x.z = __float_as_uint(b.x);
     x.w = __float_as_uint(b.y);
-    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, AUX);
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_nop 3" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);

@@ -435,8 +435,9 @@ static int launch_colfd(int M, const ColfdParams& prm, hipStream_t st) {
     const int grid = gang_grid(NQ, prm.N2 / C);
     switch (M) {
 #ifdef PBH_DIAGNOSTIC
-#define X(m) case m: { const int sp = fd4_sp() / 10;   /* A/B: 0 = default, 1 = spread deferred pairs, 2 = deferred stores, 3 = twiddle tables read for every tile */ \
-            return sp == 3 ? launch_tile_kernel(k_colfd<m, PBH_R, 2, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+#define X(m) case m: { const int sp = fd4_sp() / 10;   /* A/B: 0 = default, 1 = spread deferred pairs, 2 = deferred stores, 3 = twiddle tables read for every tile, 4 = ordinary (not nt) stores */ \
+            return sp == 4 ? launch_tile_kernel(k_colfd<m, PBH_R, 2, 1, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
+                 : sp == 3 ? launch_tile_kernel(k_colfd<m, PBH_R, 2, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
                  : sp == 2 ? launch_tile_kernel(k_colfd<m, PBH_R, 0>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
                  : sp == 1 ? launch_tile_kernel(k_colfd<m, PBH_R, 1>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16) \
                            : launch_tile_kernel(k_colfd<m, PBH_R, 2>, prm, grid, kTilePoints / PBH_R, st, lds_tile_bytes<false>() + 16); }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512) void k_fdq(const float2* __restrict__ in, floa
 // SUB = log2 of the columns of a sub-block: the same pieces with the rows of a tile 2^SUB x 128 B apart instead of 2 MiB (sub-blocks of
 // (1024, 2^SUB, 16)): is the cost of a
 // partial-line load the LINE, or the 2-MiB page each of its rows lives in?
-template <int MODE, int LW, int SW, int SUB = 0, int WC = 0>   // WC (8-byte stores): 1 = a tile's outputs as ONE contiguous 128-KiB block, 2 = rows of a tile 1 KiB apart in 8-row chunks
+template <int MODE, int LW, int SW, int SUB = 0, int WC = 0, int STAUX = 0>   // STAUX: cache policy bits of the stores (1 sc0, 2 nt, 16 sc1)   // WC (8-byte stores): 1 = a tile's outputs as ONE contiguous 128-KiB block, 2 = rows of a tile 1 KiB apart in 8-row chunks
 __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, float2* __restrict__ out, float* sink) {
     const int tid = threadIdx.x;
     const uint32_t b = blockIdx.x, xg = b & 7u, li = b >> 3;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512) void k_fdqw(const float2* __restrict__ in, flo
             if (MODE != 1) {
                 if (SW == 16) { if (i % 2 == 0) { u32x4 y; y.x = __float_as_uint(v[2 * i] + 1.f); y.y = __float_as_uint(v[2 * i + 1]); y.z = __float_as_uint(v[2 * i + 2]); y.w = __float_as_uint(v[2 * i + 3]);
                                                   __builtin_amdgcn_raw_buffer_store_b128(y, wr, voff_out, (int)((i / 2) * SOUT), 0); } }
-                else { u32x2 y; y.x = __float_as_uint(v[2 * i] + 1.f); y.y = __float_as_uint(v[2 * i + 1]); __builtin_amdgcn_raw_buffer_store_b64(y, wr, voff_out, (int)(i * SOUT), 0); }
+                else { u32x2 y; y.x = __float_as_uint(v[2 * i] + 1.f); y.y = __float_as_uint(v[2 * i + 1]); __builtin_amdgcn_raw_buffer_store_b64(y, wr, voff_out, (int)(i * SOUT), STAUX); }
             } else acc += v[2 * i] + v[2 * i + 1];
             if (MODE != 2) {
                 if (LW == 16) { if (i % 2 == 0) { const int j = i / 2; u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rdn, voff_in, (int)(j * SIN), 0); nx[4 * j] = __uint_as_float(x.x); nx[4 * j + 1] = __uint_as_float(x.y); nx[4 * j + 2] = __uint_as_float(x.z); nx[4 * j + 3] = __uint_as_float(x.w); } }
@@ -788,6 +788,14 @@ int main(int argc, char** argv) {
             W2(1, 0, "loads + stores, tile out = contiguous block", two)
             W2(2, 0, "loads + stores, 8-row chunks", two)
 #undef W2
+#define W3(AUX, M, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, 8, 8, 0, 0, AUX>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
+            W3(2, 2, "stores only, nt", 1.0 * bytes)
+            W3(16, 2, "stores only, sc1", 1.0 * bytes)
+            W3(17, 2, "stores only, sc0 sc1", 1.0 * bytes)
+            W3(3, 2, "stores only, sc0 nt", 1.0 * bytes)
+            W3(2, 0, "loads + stores, nt stores", two)
+            W3(17, 0, "loads + stores, sc0 sc1 stores", two)
+#undef W3
 #define W1(SB, M, L, St, name, by) timeit(name, by, [&] { hipLaunchKernelGGL((k_fdqw<M, L, St, SB>), dim3(256), dim3(512), 0, 0, in, a, (float*)cnt); });
             W1(6, 1, 8, 8, "rows   8 KiB apart: 8-byte loads only", 1.0 * bytes)
             W1(8, 1, 8, 8, "rows  32 KiB apart: 8-byte loads only", 1.0 * bytes)
