@@ -68,7 +68,7 @@ struct ColfdParams {
 //   kernel is bound by: 1.186 -> 1.165 ms at config 2, 25 VGPRs fewer; 0 = the tables for every tile (k_colq's way, whose tile
 //   order is not static)
 // STAUX: cache policy of the Q4 stores: 2 = nt (default: the lines are not read again before 2 GiB of other traffic have passed;
-//   1.157 -> 1.135 ms at config 2; the same hint on the row pass's and the inverse column pass's stores moved nothing: r04_ab_colfd_pacing.txt)
+//   1.157 -> 1.135 ms at config 2; the row pass's stores carry it too, the inverse column pass's and the last pass's do not: r04_ab_colfd_pacing.txt)
 template <int M, int R, int SP = 2, int TWR = 1, int STAUX = 2>
 __global__ __launch_bounds__(kTilePoints / R) void k_colfd(ColfdParams p) {
     constexpr int F = kTilePoints / M;   // columns of a tile: 4 series x C columns n2
@@ -220,7 +220,9 @@ struct RowqParams {
 //   FWD_LOADS = 0: k_rowp16's pacing, 1.16-1.18 ms at config 2; 4: 1.11-1.15; 8: 1.08-1.10; 10 (default, 256 VGPRs): 1.04-1.08; 12: 1.11.
 //   Issuing the ten EARLIER (every 2nd / 3rd tick instead of every 4th): 1.19 / 1.13; the phase row requested inside the forward
 //   transform instead of before it: no change (profiles/r04_ab_row_pacing2.txt).
-template <int R, int FWD_LOADS = 10>
+// STAUX: cache policy of the stores: 2 = nt (default) -- this pass's own time does not move, the inverse column pass that reads the
+//   rows next does (0.7255 -> 0.7137 ms at config 2, profiles/r04_ab_colfd_pacing.txt)
+template <int R, int FWD_LOADS = 10, int STAUX = 2>
 __global__ __launch_bounds__(kTilePoints / R) void k_rowq16(RowqParams p) {
     constexpr int M = kTilePoints;
     static_assert(M == 16384 && R == 32, "k_rowq16: 2^14-point rows, 32 points per thread");
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(kTilePoints / R) void k_rowq16(RowqParams p) {
         a = make_cf(__uint_as_float(x.x), __uint_as_float(x.y));
         b = make_cf(__uint_as_float(x.z), __uint_as_float(x.w));
     };
-    auto store_pair = [&](rsrc_t r, int j, cf a, cf b) { buf_store_pair(r, voff16, j * STEP16, a, b); };
+    auto store_pair = [&](rsrc_t r, int j, cf a, cf b) { buf_store_pair<STAUX>(r, voff16, j * STEP16, a, b); };
 
     uint32_t u = gg.gang;
     if (u >= nunit) return;
